@@ -1,0 +1,146 @@
+"""The CPU oracle (oracle/ref_cpu.py) against the fixtures generated from the reference's own
+modules (oracle/gen_golden.py).  CPU only; runs in the build container and on the GPU box."""
+import numpy as np
+import torch
+
+from oracle import ref_cpu
+from conftest import rel_err
+
+TOL = 2e-6   # same ATen-CPU calls as the reference: differences are thread-count/blocking noise
+
+
+def test_wavenet_encoder(golden):
+    g = golden("wavenet_enc")
+    y = ref_cpu.wavenet_forward(g.sd, "", g.ins["x"], g.meta["n_layers"], g.meta["dilation_cycle"])
+    assert rel_err(y, g.outs["y"]) < TOL
+
+
+def test_wavenet_decoder_conditioned(golden):
+    g = golden("wavenet_dec")
+    y = ref_cpu.wavenet_forward(g.sd, "", g.ins["x"], g.meta["n_layers"], g.meta["dilation_cycle"],
+                                condition=g.ins["cond"])
+    assert y.shape == g.outs["y"].shape
+    assert rel_err(y, g.outs["y"]) < TOL
+
+
+def test_convnext(golden):
+    g = golden("convnext")
+    assert rel_err(ref_cpu.convnext_block(g.sd, "", g.ins["x"]), g.outs["y"]) < TOL
+
+
+def test_activation1d(golden):
+    for kind in ("snakebeta", "snake"):
+        g = golden("activation1d_" + kind)
+        for t in g.meta["lengths"]:
+            y = ref_cpu.activation1d(g.ins[f"x{t}"], g.sd["act.alpha"], g.sd.get("act.beta", g.sd["act.alpha"]),
+                                     g.sd["upsample.filter"], g.sd["downsample.lowpass.filter"],
+                                     logscale=True, snake=(kind == "snake"))
+            assert rel_err(y, g.outs[f"y{t}"]) < TOL, (kind, t)
+
+
+def test_aa_filter_taps(golden):
+    g = golden("aa_filter")
+    assert torch.equal(ref_cpu.aa_filter12(), g.outs["taps12"])
+    # SURVEY App. A.5 prints the taps
+    assert abs(float(g.outs["taps12"][0, 0, 5]) - 0.4432097971) < 1e-9
+
+
+def test_ampblock1(golden):
+    g = golden("ampblock1")
+    y = ref_cpu.ampblock1(g.sd, "", g.ins["x"], g.meta["k"], g.meta["dilations"])
+    assert rel_err(y, g.outs["y"]) < TOL
+
+
+def test_bigvgan_tiny(golden):
+    for name in ("bigvgan_tiny", "bigvgan_tiny_snake_nowm"):
+        g = golden(name)
+        y = ref_cpu.bigvgan_forward(g.sd, g.meta["h"], g.ins["mel"])
+        assert y.shape == g.outs["audio"].shape
+        assert rel_err(y, g.outs["audio"]) < 5e-6, name
+
+
+def test_mel_basis_selfchecks(golden):
+    """Parity of the mel basis is UNPINNED by the reference (librosa absent): formula self-checks."""
+    g = golden("mel_basis")
+    for tag, (sr, n_mels, fmax) in {"24k100": (24000, 100, 12000.0), "16k80": (16000, 80, None)}.items():
+        m = ref_cpu.slaney_mel_basis(sr, 1024, n_mels, 0.0, fmax)
+        assert m.dtype == np.float32 and m.shape == (n_mels, 513)
+        assert np.array_equal(m, g.outs[tag].numpy())
+        assert m[0, 0] == 0.0 and (m >= 0).all()
+        # every filter is a single triangle: one contiguous support, one peak
+        for row in m:
+            nz = np.nonzero(row)[0]
+            assert len(nz) > 0 and nz[-1] - nz[0] + 1 == len(nz)
+        # Slaney area normalisation: integral of each triangle over Hz is ~1
+        area = m.sum(axis=1) * (sr / 1024)
+        assert np.allclose(area[10:], 1.0, atol=0.12)
+        # linear region below 1 kHz: centre spacing is constant
+        peaks = m.argmax(axis=1) * sr / 1024
+        low = peaks[peaks < 900]
+        assert np.ptp(np.diff(low)) <= 2 * sr / 1024
+
+
+def test_stft_logmel_fixture(golden):
+    g = golden("stft_logmel")
+    for tag, (sr, n_mels, fmax) in g.meta["cases"].items():
+        y = ref_cpu.stft_logmel(g.ins[tag], sr, 1024, 1024, 256, n_mels, 0.0, fmax)
+        assert y.shape == (2, n_mels, sr // 256)
+        assert rel_err(y, g.outs[tag]) < TOL
+
+
+def test_stft_against_direct_dft():
+    """torch.stft is the reference's own call; check the oracle's framing/padding/window
+    against a float64 direct DFT."""
+    torch.manual_seed(3)
+    L, n_fft, hop = 2000, 256, 64
+    y = torch.randn(1, L)
+    mag = ref_cpu.stft_logmel(y, 16000, n_fft, n_fft, hop, 20, return_linear=True)[0].double()
+    pad = (n_fft - hop) // 2
+    yp = torch.nn.functional.pad(y.double().unsqueeze(1), (pad, pad), mode="reflect")[0, 0]
+    n = torch.arange(n_fft, dtype=torch.float64)
+    w = 0.5 - 0.5 * torch.cos(2 * torch.pi * n / n_fft)
+    T = L // hop
+    assert mag.shape == (n_fft // 2 + 1, T)
+    k = torch.arange(n_fft // 2 + 1, dtype=torch.float64)
+    e = torch.exp(-2j * torch.pi * k[:, None] * n[None, :] / n_fft)
+    for t in (0, 1, T // 2, T - 1):
+        fr = yp[t * hop:t * hop + n_fft] * w
+        X = (e * fr[None, :].to(torch.complex128)).sum(1)
+        ref = torch.sqrt(X.real ** 2 + X.imag ** 2 + 1e-9)
+        assert torch.allclose(mag[:, t], ref, rtol=1e-4, atol=1e-4)
+
+
+def test_fsq_fixture_and_invariants(golden):
+    for levels in ([7, 5, 5], [8, 6]):
+        g = golden("fsq_" + "x".join(map(str, levels)))
+        n_codes = int(np.prod(levels))
+        for pb in (1, 0):
+            ids, pre = ref_cpu.grouped_fsq_encode(g.sd, "", g.ins["z"], 1, levels, prebound=bool(pb),
+                                                  return_prequant=True)
+            assert torch.equal(ids, g.outs[f"ids_prebound{pb}"])
+            assert ids.dtype == torch.int32 and int(ids.min()) >= 0 and int(ids.max()) < n_codes
+        # decode(encode) round trip on the implicit codebook: ids -> codes -> ids
+        codes = ref_cpu.fsq_codes_from_indices(torch.arange(n_codes), levels)
+        hw = torch.tensor(levels) // 2
+        back = ref_cpu.fsq_indices_from_prequant(codes * hw, levels)
+        assert torch.equal(back, torch.arange(n_codes, dtype=torch.int32))
+        deq = ref_cpu.grouped_fsq_decode(g.sd, "", g.ins["all_ids"], levels)
+        assert torch.equal(deq, g.outs["dequant"])
+    # reference-side invariants that pin the codebook size: 175 ids, silence frame < 175
+    assert int(np.prod([7, 5, 5])) == 175
+    assert max([0, 0, 29, 174, 0, 6, 0, 146, 146, 6]) < 175
+
+
+def test_schedule_fixture(golden):
+    """utils/schedule.py:4-25 restated inline (host logic used by train entry point later)."""
+    import math
+    g = golden("schedule")
+
+    def lr_lambda(step, warm=100, total=1000000, final=0.05, cycles=0.5):
+        if step < warm:
+            return step / max(1, warm)
+        prog = (step - warm) / max(1, total - warm)
+        return max(final, 0.5 * (1.0 + math.cos(math.pi * cycles * 2.0 * prog)))
+
+    vals = torch.tensor([lr_lambda(int(s)) for s in g.ins["steps"]])
+    assert torch.allclose(vals, g.outs["lr"], atol=1e-7)
