@@ -1,0 +1,111 @@
+// Error string + launch-timing plumbing of libdmel_hip.so.
+#include "common.h"
+
+#include <map>
+#include <mutex>
+
+namespace dmel {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+// ---- per-family hipEvent timing --------------------------------------------------------------
+struct ProfRec {
+  hipEvent_t start, stop;
+  int family;
+  double flops, bytes;
+};
+struct ProfState {
+  std::mutex mu;
+  bool on = false;
+  std::vector<std::string> families;
+  std::vector<ProfRec> recs;
+};
+static ProfState& prof() {
+  static ProfState s;
+  return s;
+}
+
+ProfScope::ProfScope(const char* family, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
+  ProfState& p = prof();
+  if (!p.on) return;
+  std::lock_guard<std::mutex> lk(p.mu);
+  int fam = -1;
+  for (size_t i = 0; i < p.families.size(); ++i)
+    if (p.families[i] == family) fam = (int)i;
+  if (fam < 0) {
+    p.families.push_back(family);
+    fam = (int)p.families.size() - 1;
+  }
+  ProfRec r;
+  r.family = fam;
+  r.flops = flops;
+  r.bytes = bytes;
+  if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
+  (void)hipEventRecord(r.start, s);
+  p.recs.push_back(r);
+  slot = (int)p.recs.size() - 1;
+}
+
+ProfScope::~ProfScope() {
+  if (slot < 0) return;
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  (void)hipEventRecord(p.recs[slot].stop, stream);
+}
+
+}  // namespace dmel
+
+using namespace dmel;
+
+extern "C" const char* dmel_last_error(void) { return g_err.c_str(); }
+extern "C" int dmel_abi_version(void) { return 1; }
+
+extern "C" int dmel_prof_enable(int on) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  p.on = on != 0;
+  return DMEL_OK;
+}
+
+extern "C" int dmel_prof_reset(void) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  for (auto& r : p.recs) {
+    (void)hipEventDestroy(r.start);
+    (void)hipEventDestroy(r.stop);
+  }
+  p.recs.clear();
+  return DMEL_OK;
+}
+
+extern "C" int dmel_prof_read(const char* family, int64_t* launches, double* total_ms, double* total_flops,
+                              double* total_bytes) {
+  ProfState& p = prof();
+  std::lock_guard<std::mutex> lk(p.mu);
+  int64_t n = 0;
+  double ms = 0, fl = 0, by = 0;
+  for (auto& r : p.recs) {
+    if (p.families[r.family] != family) continue;
+    if (hipEventSynchronize(r.stop) != hipSuccess) continue;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.start, r.stop) != hipSuccess) continue;
+    ++n;
+    ms += t;
+    fl += r.flops;
+    by += r.bytes;
+  }
+  if (launches) *launches = n;
+  if (total_ms) *total_ms = ms;
+  if (total_flops) *total_flops = fl;
+  if (total_bytes) *total_bytes = by;
+  return DMEL_OK;
+}

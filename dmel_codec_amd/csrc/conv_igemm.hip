@@ -1,0 +1,336 @@
+// Implicit-GEMM 1-D convolution on the fp32-input MFMA (v_mfma_f32_32x32x2_f32) for gfx950.
+//
+// One kernel serves every dense conv of the path: WaveNet dilated k3 convs with the 1x1 condition
+// projection concatenated along K and the sigmoid*tanh gate in the epilogue; the 1x1 output projection with
+// the residual / skip update in the epilogue; BigVGAN's k in {3,7,11}, dilation in {1,3,5} convs with the
+// residual add and the 1/3 branch average in the epilogue; transposed convs as phase-major sub-convolutions;
+// the ConvNeXt pointwise Linears; conv_pre / conv_post.
+//
+// GEMM view per batch item:  D[m, t] = sum_{ci, tap} W[m, ci, tap] * x[ci, t + tap*dil - pad]
+//   M = output rows (packed, see conv.h), N = time, K = Cin * taps, walked in steps of (16 channels, 1 tap).
+// Layout: activations stay (B, C, T) with T contiguous, so a K-step's B operand is 16 rows of the staged
+// x tile and the tap is just a column shift inside LDS (x is read from HBM once per 16-channel chunk, not
+// once per tap).  Weights are pre-tiled on the host to [m-block][step][16][BM], so a step's A tile is one
+// contiguous 16*BM*4-byte run (float4, fully coalesced) and both LDS fragment reads are 32 consecutive
+// dwords per half-wave: bank-conflict free for any tap shift.
+// Numerics: exact fp32 fma chains in K order (MI355X_MICROARCH: f32 MFMA == fmaf chain), so results differ
+// from ATen only by summation order.
+#include "conv.h"
+
+namespace dmel {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+struct SegArgs {
+  const float* x;
+  int64_t bstride, cstride, Tin;
+  const int64_t* in_len;
+  float in_scale;
+  int Cin, nchunk, taps, dil, pad_left, tstride, toff;
+};
+
+struct KArgs {
+  SegArgs seg[2];
+  int nseg, steps;
+  const float* w;
+  const float* bias;
+  int64_t Tcols;
+  int mode, act, C, RP, phases, out_tstride, phase_base, accumulate, len_div, skip_first;
+  float out_div;
+  float* y;
+  int64_t y_bs, y_cs, Tout;
+  const float* res;
+  int64_t res_bs, res_cs;
+  const float* row_scale;
+  const int64_t* out_len;
+  float* skip;
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) {
+  switch (act) {
+    case ACT_SILU: return v / (1.f + expf(-v));
+    case ACT_TANH: return tanhf(v);
+    case ACT_CLAMP1: return fminf(fmaxf(v, -1.f), 1.f);
+    case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+    default: return v;
+  }
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArgs a) {
+  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NTHR = 64 * WAVES_M * WAVES_N;
+  constexpr int XS = BN + 64;                      // staged x row: BN columns + up to 64 halo
+  constexpr int XL = (kCK * XS + NTHR - 1) / NTHR; // x elements per thread per chunk
+  constexpr int WL = (kCK * BM / 4 + NTHR - 1) / NTHR;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* Xs = smem;                  // [2][kCK][XS]
+  float* Ws = smem + 2 * kCK * XS;   // [2][kCK][BM]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int64_t q0 = (int64_t)blockIdx.x * BN;
+  const int mblk = blockIdx.y, b = blockIdx.z;
+  const int lb = b / a.len_div;
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const float* wbase = a.w + (size_t)mblk * a.steps * (kCK * BM);
+  float xr[XL];
+  float4 wr[WL];
+
+  auto load_x = [&](int sg, int chunk) {
+    const SegArgs& s = a.seg[sg];
+    const int wx = BN + (s.taps - 1) * s.dil;
+    const float* xb = s.x + (int64_t)b * s.bstride;
+    const int64_t lim = s.in_len ? min(s.in_len[lb], s.Tin) : s.Tin;
+    const int64_t tau0 = q0 * s.tstride + s.toff - s.pad_left;
+#pragma unroll
+    for (int it = 0; it < XL; ++it) {
+      const int i = tid + it * NTHR;
+      const int r = i / XS, j = i - r * XS;
+      const int ci = chunk * kCK + r;
+      const int64_t tau = tau0 + (int64_t)j * s.tstride;
+      float v = 0.f;
+      if (i < kCK * XS && j < wx && ci < s.Cin && tau >= 0 && tau < lim) v = xb[(int64_t)ci * s.cstride + tau] * s.in_scale;
+      xr[it] = v;
+    }
+  };
+  auto store_x = [&](float* dst) {
+#pragma unroll
+    for (int it = 0; it < XL; ++it) {
+      const int i = tid + it * NTHR;
+      if (i < kCK * XS) dst[i] = xr[it];
+    }
+  };
+  auto load_w = [&](int step) {
+    const float4* src = reinterpret_cast<const float4*>(wbase + (size_t)step * (kCK * BM));
+#pragma unroll
+    for (int it = 0; it < WL; ++it) {
+      const int i = tid + it * NTHR;
+      if (i < kCK * BM / 4) wr[it] = src[i];
+    }
+  };
+  auto store_w = [&](float* dst) {
+#pragma unroll
+    for (int it = 0; it < WL; ++it) {
+      const int i = tid + it * NTHR;
+      if (i < kCK * BM / 4) reinterpret_cast<float4*>(dst)[i] = wr[it];
+    }
+  };
+
+  int sg = 0, chunk = 0, tap = 0, xbuf = 0;
+  load_x(0, 0);
+  load_w(0);
+  store_x(Xs);
+  store_w(Ws);
+  __syncthreads();
+
+  for (int s = 0; s < a.steps; ++s) {
+    int nsg = sg, nchunk = chunk, ntap = tap + 1;
+    bool newx = false;
+    if (ntap == a.seg[sg].taps) {
+      ntap = 0;
+      ++nchunk;
+      newx = true;
+      if (nchunk == a.seg[sg].nchunk) { nchunk = 0; ++nsg; }
+    }
+    const bool has_next = s + 1 < a.steps;
+    if (has_next) {
+      load_w(s + 1);
+      if (newx) load_x(nsg, nchunk);
+    }
+    {
+      const float* wp = Ws + (s & 1) * (kCK * BM) + wave_m * (MT * 32) + l31;
+      const float* xp = Xs + xbuf * (kCK * XS) + wave_n * (NT * 32) + l31 + tap * a.seg[sg].dil;
+#pragma unroll
+      for (int kk = 0; kk < kCK / 2; ++kk) {
+        const int k = 2 * kk + h;
+        float av[MT], bv[NT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) av[mi] = wp[k * BM + mi * 32];
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) bv[ni] = xp[k * XS + ni * 32];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bv[ni], acc[mi][ni], 0, 0, 0);
+      }
+    }
+    if (has_next) {
+      store_w(Ws + ((s + 1) & 1) * (kCK * BM));
+      if (newx) store_x(Xs + (xbuf ^ 1) * (kCK * XS));
+    }
+    __syncthreads();
+    if (newx) xbuf ^= 1;
+    sg = nsg; chunk = nchunk; tap = ntap;
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const int64_t olim = a.out_len ? a.out_len[lb] : (int64_t)1 << 62;
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;  // first packed row of this 32-row MFMA tile
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int64_t q = q0 + wave_n * (NT * 32) + ni * 32 + l31;
+      if (q >= a.Tcols) continue;
+      if (a.mode == EPI_LINEAR) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int ph = m / a.RP, co = m - ph * a.RP;
+          if (co >= a.C || ph >= a.phases) continue;
+          const int64_t t = q * a.out_tstride + a.phase_base + ph;
+          if (t >= a.Tout) continue;
+          float v = act_apply(acc[mi][ni][r] + a.bias[m], a.act);
+          if (a.row_scale) v *= a.row_scale[co];
+          if (a.res) v += a.res[(int64_t)b * a.res_bs + (int64_t)co * a.res_cs + t];
+          float* yp = a.y + (int64_t)b * a.y_bs + (int64_t)co * a.y_cs + t;
+          if (a.accumulate) v += *yp;
+          if (a.out_div != 1.f) v = v / a.out_div;
+          if (t >= olim) v = 0.f;
+          *yp = v;
+        }
+      } else {
+        const int q32 = mtile >> 5;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          if ((r >> 2) & 1) continue;  // odd 4-groups are the partner rows
+          const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
+          const int c = q32 * 16 + ((rho >> 3) >> 1) * 8 + (rho & 7);
+          if (c >= a.C) continue;
+          const float v0 = acc[mi][ni][r] + a.bias[mtile + rho];
+          const float v1 = acc[mi][ni][r + 4] + a.bias[mtile + rho + 8];
+          const int64_t off = (int64_t)b * a.y_bs + (int64_t)c * a.y_cs + q;
+          if (a.mode == EPI_GATE) {
+            a.y[off] = (1.f / (1.f + expf(-v0))) * tanhf(v1);
+          } else {
+            a.y[off] = (a.y[off] + v0) / 1.41421356237309504880f;
+            a.skip[off] = a.skip_first ? v1 : a.skip[off] + v1;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int MT, int NT> static int launch_t(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  const size_t lds = (size_t)(2 * kCK * (BN + 64) + 2 * kCK * BM) * sizeof(float);
+  dim3 grid((unsigned)((ka.Tcols + BN - 1) / BN), (unsigned)mblocks, (unsigned)B);
+  if (grid.y > 65535 || grid.z > 65535) {
+    set_error("conv_igemm: grid too large (mblocks %u, batch %u)", grid.y, grid.z);
+    return DMEL_EINVAL;
+  }
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), lds, st, ka);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+static int pick_bn(int64_t T, std::initializer_list<int> cands) {
+  int best = 0;
+  int64_t best_cols = 0;
+  for (int bn : cands) {
+    int64_t cols = (T + bn - 1) / bn * bn;
+    if (best == 0 || cols < best_cols || (cols == best_cols && bn > best)) { best = bn; best_cols = cols; }
+  }
+  return best;
+}
+
+int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
+  KArgs ka{};
+  const PackDesc& d = pc.d;
+  ka.nseg = d.nseg;
+  ka.steps = pc.steps;
+  int max_halo = 0;
+  for (int s = 0; s < d.nseg; ++s) {
+    const SegDesc& sd = d.seg[s];
+    SegArgs& o = ka.seg[s];
+    DMEL_CHECK_ARG(r.seg[s].x != nullptr, "conv: input pointer of segment %d is NULL", s);
+    DMEL_CHECK_ARG(sd.taps == 1 || sd.tstride == 1, "conv: taps>1 with strided input unsupported");
+    o.x = r.seg[s].x; o.bstride = r.seg[s].bstride; o.cstride = r.seg[s].cstride; o.Tin = r.seg[s].Tin;
+    o.in_len = r.seg[s].in_len; o.in_scale = r.seg[s].in_scale;
+    o.Cin = sd.Cin; o.nchunk = (sd.Cin + kCK - 1) / kCK; o.taps = sd.taps; o.dil = sd.dil;
+    o.pad_left = sd.pad_left; o.tstride = sd.tstride; o.toff = sd.toff;
+    max_halo = std::max(max_halo, (sd.taps - 1) * sd.dil);
+  }
+  if (max_halo > 64) {
+    set_error("conv_igemm: receptive field (taps-1)*dilation = %d exceeds the 64-sample LDS halo", max_halo);
+    return DMEL_EUNSUPPORTED;
+  }
+  DMEL_CHECK_ARG(r.y != nullptr && r.B > 0 && r.Tcols > 0, "conv: bad output/batch/length");
+  DMEL_CHECK_ARG(d.mode != EPI_RESSKIP || r.skip != nullptr, "conv: skip buffer missing");
+  ka.w = pc.w.as<float>(); ka.bias = pc.bias.as<float>();
+  ka.Tcols = r.Tcols; ka.mode = d.mode; ka.act = r.act; ka.C = d.C; ka.RP = pc.RP; ka.phases = d.phases;
+  ka.out_tstride = r.out_tstride; ka.phase_base = r.phase_base; ka.accumulate = r.accumulate;
+  ka.len_div = r.len_div > 0 ? r.len_div : 1; ka.skip_first = r.skip_first; ka.out_div = r.out_div;
+  ka.y = r.y; ka.y_bs = r.y_bs; ka.y_cs = r.y_cs; ka.Tout = r.Tout > 0 ? r.Tout : r.Tcols * r.out_tstride;
+  ka.res = r.res; ka.res_bs = r.res_bs; ka.res_cs = r.res_cs; ka.row_scale = r.row_scale;
+  ka.out_len = r.out_len; ka.skip = r.skip;
+  const int mblocks = pc.Mpad / pc.BM;
+  const double rows_real = (d.mode == EPI_LINEAR ? (double)d.C * d.phases : 2.0 * d.C);
+  ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, 0.0);
+  switch (pc.BM) {
+    case 128:
+      switch (pick_bn(r.Tcols, {128, 96})) {
+        case 128: return launch_t<2, 2, 2, 2>(ka, r.B, mblocks, stream);
+        default: return launch_t<4, 1, 1, 3>(ka, r.B, mblocks, stream);
+      }
+    case 64:
+      switch (pick_bn(r.Tcols, {128, 96})) {
+        case 128: return launch_t<2, 2, 1, 2>(ka, r.B, mblocks, stream);
+        default: return launch_t<2, 1, 1, 3>(ka, r.B, mblocks, stream);
+      }
+    default:
+      switch (pick_bn(r.Tcols, {256, 128, 96})) {
+        case 256: return launch_t<1, 4, 1, 2>(ka, r.B, mblocks, stream);
+        case 128: return launch_t<1, 4, 1, 1>(ka, r.B, mblocks, stream);
+        default: return launch_t<1, 3, 1, 1>(ka, r.B, mblocks, stream);
+      }
+  }
+}
+
+}  // namespace dmel
+
+using namespace dmel;
+
+// ---- single-op C ABI (tests / module mirrors) ---------------------------------------------------
+struct dmel_conv {
+  PackedConv pc;
+  int Cout, Cin, k, dil;
+};
+
+extern "C" int dmel_conv_create(dmel_conv** out, const float* w_host, const float* bias_host, int Cout, int Cin, int k,
+                                int dilation) {
+  DMEL_CHECK_ARG(out && w_host, "NULL argument");
+  DMEL_CHECK_ARG(Cout > 0 && Cin > 0 && k > 0 && (k % 2) == 1 && dilation > 0, "conv: bad shape (odd k required)");
+  auto* c = new dmel_conv();
+  c->Cout = Cout; c->Cin = Cin; c->k = k; c->dil = dilation;
+  PackDesc d;
+  d.mode = EPI_LINEAR; d.nseg = 1; d.C = Cout; d.phases = 1;
+  d.seg[0].Cin = Cin; d.seg[0].taps = k; d.seg[0].dil = dilation; d.seg[0].pad_left = dilation * (k - 1) / 2;
+  int rc = pack_conv(c->pc, d,
+                     [&](int, int row, int ci, int tap) { return w_host[((size_t)row * Cin + ci) * k + tap]; },
+                     [&](int row) { return bias_host ? bias_host[row] : 0.f; });
+  if (rc != DMEL_OK) { delete c; return rc; }
+  *out = c;
+  return DMEL_OK;
+}
+
+extern "C" void dmel_conv_destroy(dmel_conv* c) { delete c; }
+
+extern "C" int dmel_conv_forward(const dmel_conv* c, const float* x, float* y, int B, int64_t T, void* stream) {
+  DMEL_CHECK_ARG(c && x && y, "NULL argument");
+  ConvRun r;
+  r.seg[0].x = x; r.seg[0].bstride = (int64_t)c->Cin * T; r.seg[0].cstride = T; r.seg[0].Tin = T;
+  r.B = B; r.Tcols = T; r.y = y; r.y_bs = (int64_t)c->Cout * T; r.y_cs = T; r.Tout = T;
+  return launch_conv(c->pc, r, (hipStream_t)stream);
+}

@@ -1,0 +1,683 @@
+// Module-level orchestration: WaveNet, DownsampleFiniteScalarQuantize, BigVGAN.
+// Host code only: consumes reference state-dict tensors, folds weight norm, re-tiles weights for the MFMA conv
+// kernel and issues the kernel sequence of one forward on the caller's stream (no allocation, no sync).
+#include <cmath>
+#include <map>
+#include <memory>
+
+#include "ops.h"
+
+using namespace dmel;
+
+namespace {
+
+struct HostTensor {
+  std::vector<float> v;
+  std::vector<int64_t> shape;
+  int64_t numel() const { return (int64_t)v.size(); }
+};
+
+struct TensorStore {
+  std::map<std::string, HostTensor> t;
+  int set(const char* key, const float* data, const int64_t* shape, int ndim) {
+    DMEL_CHECK_ARG(key && data && shape && ndim >= 0 && ndim <= 4, "set_tensor: bad argument");
+    HostTensor h;
+    int64_t n = 1;
+    for (int i = 0; i < ndim; ++i) { h.shape.push_back(shape[i]); n *= shape[i]; }
+    h.v.assign(data, data + n);
+    t[key] = std::move(h);
+    return DMEL_OK;
+  }
+  const HostTensor* find(const std::string& k) const {
+    auto it = t.find(k);
+    return it == t.end() ? nullptr : &it->second;
+  }
+  // exact-shape lookup; sets the error and returns nullptr when missing or mis-shaped
+  const HostTensor* need(const std::string& k, std::initializer_list<int64_t> shape) const {
+    const HostTensor* h = find(k);
+    if (!h) { set_error("missing state-dict tensor '%s'", k.c_str()); return nullptr; }
+    if (h->shape != std::vector<int64_t>(shape)) {
+      std::string got, want;
+      for (auto s : h->shape) got += std::to_string(s) + ",";
+      for (auto s : shape) want += std::to_string(s) + ",";
+      set_error("tensor '%s' has shape (%s) but (%s) is required", k.c_str(), got.c_str(), want.c_str());
+      return nullptr;
+    }
+    return h;
+  }
+  // conv weight with optional old-style weight norm (weight_g, weight_v; norm over all dims but 0), torch._weight_norm
+  bool conv_weight(const std::string& prefix, std::initializer_list<int64_t> shape, std::vector<float>& out) const {
+    if (find(prefix + "weight")) {
+      const HostTensor* w = need(prefix + "weight", shape);
+      if (!w) return false;
+      out = w->v;
+      return true;
+    }
+    const HostTensor* v = need(prefix + "weight_v", shape);
+    if (!v) { set_error("missing state-dict tensor '%sweight' (or weight_g/weight_v)", prefix.c_str()); return false; }
+    const HostTensor* g = find(prefix + "weight_g");
+    const int64_t n0 = *shape.begin();
+    if (!g || g->numel() != n0) { set_error("missing or mis-shaped '%sweight_g'", prefix.c_str()); return false; }
+    const int64_t inner = v->numel() / n0;
+    out.resize(v->v.size());
+    for (int64_t i = 0; i < n0; ++i) {
+      double ss = 0;
+      for (int64_t j = 0; j < inner; ++j) ss += (double)v->v[i * inner + j] * v->v[i * inner + j];
+      const float scale = g->v[i] / (float)std::sqrt(ss);
+      for (int64_t j = 0; j < inner; ++j) out[i * inner + j] = v->v[i * inner + j] * scale;
+    }
+    return true;
+  }
+};
+
+int upload_vec(DevBuf& d, const std::vector<float>& v) { return d.upload(v.data(), v.size() * sizeof(float)); }
+
+ConvRun run_1seg(const float* x, int Cin, int64_t Tin, float* y, int Cout, int64_t Tout, int B) {
+  ConvRun r;
+  r.seg[0].x = x; r.seg[0].bstride = (int64_t)Cin * Tin; r.seg[0].cstride = Tin; r.seg[0].Tin = Tin;
+  r.B = B; r.Tcols = Tout; r.y = y; r.y_bs = (int64_t)Cout * Tout; r.y_cs = Tout; r.Tout = Tout;
+  return r;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// WaveNet                                               models/modules/wavenet.py:138-225
+// =====================================================================================================
+struct dmel_wavenet {
+  int Cin, Cout, C, L, cycle, Ccond;
+  TensorStore ts;
+  bool ready = false;
+  bool has_in = false, has_out = false;
+  PackedConv in_proj, skip_proj, out_proj;
+  std::vector<PackedConv> gate, resskip;
+};
+
+extern "C" int dmel_wavenet_create(dmel_wavenet** out, int input_channels, int output_channels, int residual_channels,
+                                   int residual_layers, int dilation_cycle, int condition_channels) {
+  DMEL_CHECK_ARG(out, "NULL out");
+  DMEL_CHECK_ARG(residual_channels > 0 && residual_layers > 0 && dilation_cycle >= 0 && condition_channels >= 0,
+                 "wavenet: bad configuration");
+  auto* m = new dmel_wavenet();
+  m->C = residual_channels;
+  m->Cin = input_channels > 0 ? input_channels : residual_channels;
+  m->Cout = output_channels > 0 ? output_channels : residual_channels;
+  m->L = residual_layers; m->cycle = dilation_cycle; m->Ccond = condition_channels;
+  m->has_in = m->Cin != m->C;     // wavenet.py:152-156
+  m->has_out = m->Cout != m->C;   // wavenet.py:181-186
+  *out = m;
+  return DMEL_OK;
+}
+extern "C" void dmel_wavenet_destroy(dmel_wavenet* m) { delete m; }
+extern "C" int dmel_wavenet_set_tensor(dmel_wavenet* m, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  m->ready = false;
+  return m->ts.set(key, data, shape, ndim);
+}
+
+static int pack_pointwise(PackedConv& pc, const TensorStore& ts, const std::string& prefix, int Cout, int Cin) {
+  const HostTensor* w = ts.need(prefix + "weight", {Cout, Cin, 1});
+  const HostTensor* b = ts.need(prefix + "bias", {Cout});
+  if (!w || !b) return DMEL_EMISSING;
+  PackDesc d;
+  d.mode = EPI_LINEAR; d.nseg = 1; d.C = Cout; d.seg[0].Cin = Cin;
+  return pack_conv(pc, d, [&](int, int row, int ci, int) { return w->v[(size_t)row * Cin + ci]; },
+                   [&](int row) { return b->v[row]; });
+}
+
+extern "C" int dmel_wavenet_finalize(dmel_wavenet* m) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  const int C = m->C;
+  if (m->has_in) DMEL_TRY(pack_pointwise(m->in_proj, m->ts, "input_projection.conv.", C, m->Cin));
+  m->gate.clear(); m->resskip.clear();
+  m->gate.resize(m->L); m->resskip.resize(m->L);
+  for (int i = 0; i < m->L; ++i) {
+    const std::string p = "residual_layers." + std::to_string(i) + ".";
+    const int dil = m->cycle ? 1 << (i % m->cycle) : 1;   // wavenet.py:169
+    const HostTensor* cw = m->ts.need(p + "conv_layer.conv.weight", {2 * C, C, 3});
+    const HostTensor* cb = m->ts.need(p + "conv_layer.conv.bias", {2 * C});
+    const HostTensor* ow = m->ts.need(p + "output_projection.conv.weight", {2 * C, C, 1});
+    const HostTensor* ob = m->ts.need(p + "output_projection.conv.bias", {2 * C});
+    if (!cw || !cb || !ow || !ob) return DMEL_EMISSING;
+    const HostTensor *qw = nullptr, *qb = nullptr;
+    if (m->Ccond) {
+      qw = m->ts.need(p + "condition_projection.conv.weight", {2 * C, m->Ccond, 1});
+      qb = m->ts.need(p + "condition_projection.conv.bias", {2 * C});
+      if (!qw || !qb) return DMEL_EMISSING;
+    }
+    PackDesc d;
+    d.mode = EPI_GATE; d.C = C; d.nseg = m->Ccond ? 2 : 1;
+    d.seg[0].Cin = C; d.seg[0].taps = 3; d.seg[0].dil = dil; d.seg[0].pad_left = dil;
+    d.seg[1].Cin = m->Ccond;
+    const int Cc = m->Ccond;
+    DMEL_TRY(pack_conv(m->gate[i], d,
+                       [&](int sg, int row, int ci, int tap) {
+                         return sg == 0 ? cw->v[((size_t)row * C + ci) * 3 + tap] : qw->v[(size_t)row * Cc + ci];
+                       },
+                       [&](int row) { return cb->v[row] + (qb ? qb->v[row] : 0.f); }));
+    PackDesc e;
+    e.mode = EPI_RESSKIP; e.C = C; e.nseg = 1; e.seg[0].Cin = C;
+    DMEL_TRY(pack_conv(m->resskip[i], e, [&](int, int row, int ci, int) { return ow->v[(size_t)row * C + ci]; },
+                       [&](int row) { return ob->v[row]; }));
+  }
+  DMEL_TRY(pack_pointwise(m->skip_proj, m->ts, "skip_projection.conv.", C, C));
+  if (m->has_out) DMEL_TRY(pack_pointwise(m->out_proj, m->ts, "output_projection.conv.", m->Cout, C));
+  m->ts.t.clear();
+  m->ready = true;
+  return DMEL_OK;
+}
+
+static size_t wavenet_plan(const dmel_wavenet* m, int N, int64_t T, void* ws, float** xb, float** zb, float** sb, float** tb) {
+  Arena a(ws, (size_t)-1);
+  const size_t n = (size_t)N * m->C * T;
+  float* x = a.take<float>(n);
+  float* z = a.take<float>(n);
+  float* s = a.take<float>(n);
+  float* t = m->has_out ? a.take<float>(n) : nullptr;
+  if (xb) { *xb = x; *zb = z; *sb = s; *tb = t; }
+  return align_up(a.off, 256);
+}
+
+extern "C" size_t dmel_wavenet_workspace_bytes(const dmel_wavenet* m, int N, int64_t T) {
+  if (!m || N <= 0 || T <= 0) return 0;
+  return wavenet_plan(m, N, T, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const float* condition, float* y, int N, int64_t T,
+                                    const int64_t* in_lengths, const int64_t* out_lengths, int group_repeat, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(m && x && y && workspace, "wavenet_forward: NULL argument");
+  if (!m->ready) { set_error("wavenet_forward: handle not finalized"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG((m->Ccond != 0) == (condition != nullptr), "wavenet_forward: condition tensor does not match the configuration");
+  DMEL_CHECK_ARG(N > 0 && T > 0, "wavenet_forward: bad shape");
+  float *xb, *zb, *sb, *tb;
+  const size_t need = wavenet_plan(m, N, T, workspace, &xb, &zb, &sb, &tb);
+  DMEL_CHECK_ARG(workspace_bytes >= need, "wavenet_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = m->C, div = group_repeat > 0 ? group_repeat : 1;
+
+  if (m->has_in) {  // wavenet.py:205-207: 1x1 projection + SiLU
+    ConvRun r = run_1seg(x, m->Cin, T, xb, C, T, N);
+    r.seg[0].in_len = in_lengths; r.len_div = div; r.act = ACT_SILU;
+    DMEL_TRY(launch_conv(m->in_proj, r, st));
+  } else {
+    DMEL_TRY(launch_masked_copy(x, xb, in_lengths, div, N, C, T, st));
+  }
+  for (int i = 0; i < m->L; ++i) {  // wavenet.py:116-135
+    ConvRun g = run_1seg(xb, C, T, zb, C, T, N);
+    if (m->Ccond) {
+      g.seg[1].x = condition; g.seg[1].bstride = (int64_t)m->Ccond * T; g.seg[1].cstride = T; g.seg[1].Tin = T;
+    }
+    DMEL_TRY(launch_conv(m->gate[i], g, st));
+    ConvRun r = run_1seg(zb, C, T, xb, C, T, N);
+    r.skip = sb; r.skip_first = (i == 0);
+    DMEL_TRY(launch_conv(m->resskip[i], r, st));
+  }
+  {  // wavenet.py:218-223
+    ConvRun r = run_1seg(sb, C, T, m->has_out ? tb : y, C, T, N);
+    r.seg[0].in_scale = (float)(1.0 / std::sqrt((double)m->L));
+    if (m->has_out) r.act = ACT_SILU;
+    else { r.out_len = out_lengths; r.len_div = div; }
+    DMEL_TRY(launch_conv(m->skip_proj, r, st));
+    if (m->has_out) {
+      ConvRun o = run_1seg(tb, C, T, y, m->Cout, T, N);
+      o.out_len = out_lengths; o.len_div = div;
+      DMEL_TRY(launch_conv(m->out_proj, o, st));
+    }
+  }
+  return DMEL_OK;
+}
+
+// =====================================================================================================
+// DownsampleFiniteScalarQuantize (is_dmel)          models/modules/dowmsample_fsq.py:124-147
+// =====================================================================================================
+namespace {
+struct ConvNeXt {                // firefly.py:337-402
+  DevBuf dw_w, dw_b, ln_w, ln_b, gamma;
+  PackedConv pw1, pw2;
+};
+int build_convnext(ConvNeXt& cx, const TensorStore& ts, const std::string& p, int C) {
+  const HostTensor* dw = ts.need(p + "dwconv.weight", {C, 1, 7});
+  const HostTensor* db = ts.need(p + "dwconv.bias", {C});
+  const HostTensor* lw = ts.need(p + "norm.weight", {C});
+  const HostTensor* lb = ts.need(p + "norm.bias", {C});
+  const HostTensor* w1 = ts.need(p + "pwconv1.weight", {4 * C, C});
+  const HostTensor* b1 = ts.need(p + "pwconv1.bias", {4 * C});
+  const HostTensor* w2 = ts.need(p + "pwconv2.weight", {C, 4 * C});
+  const HostTensor* b2 = ts.need(p + "pwconv2.bias", {C});
+  const HostTensor* ga = ts.need(p + "gamma", {C});
+  if (!dw || !db || !lw || !lb || !w1 || !b1 || !w2 || !b2 || !ga) return DMEL_EMISSING;
+  DMEL_TRY(upload_vec(cx.dw_w, dw->v)); DMEL_TRY(upload_vec(cx.dw_b, db->v));
+  DMEL_TRY(upload_vec(cx.ln_w, lw->v)); DMEL_TRY(upload_vec(cx.ln_b, lb->v));
+  DMEL_TRY(upload_vec(cx.gamma, ga->v));
+  PackDesc d;
+  d.mode = EPI_LINEAR; d.nseg = 1; d.C = 4 * C; d.seg[0].Cin = C;
+  DMEL_TRY(pack_conv(cx.pw1, d, [&](int, int row, int ci, int) { return w1->v[(size_t)row * C + ci]; },
+                     [&](int row) { return b1->v[row]; }));
+  d.C = C; d.seg[0].Cin = 4 * C;
+  DMEL_TRY(pack_conv(cx.pw2, d, [&](int, int row, int ci, int) { return w2->v[(size_t)row * 4 * C + ci]; },
+                     [&](int row) { return b2->v[row]; }));
+  return DMEL_OK;
+}
+// y = x + gamma * pwconv2(gelu(pwconv1(LN(dwconv(x)))))      x, y: (N, C, T); y may alias x; h1: (N,C,T), h2: (N,4C,T)
+int run_convnext(const ConvNeXt& cx, const float* x, float* y, float* h1, float* h2, int N, int C, int64_t T, hipStream_t st) {
+  DMEL_TRY(launch_dwconv_ln(x, h1, cx.dw_w.as<float>(), cx.dw_b.as<float>(), cx.ln_w.as<float>(), cx.ln_b.as<float>(), N, C, T, st));
+  ConvRun a = run_1seg(h1, C, T, h2, 4 * C, T, N);
+  a.act = ACT_GELU;
+  DMEL_TRY(launch_conv(cx.pw1, a, st));
+  ConvRun b = run_1seg(h2, 4 * C, T, y, C, T, N);
+  b.row_scale = cx.gamma.as<float>();
+  b.res = x; b.res_bs = (int64_t)C * T; b.res_cs = T;
+  return launch_conv(cx.pw2, b, st);
+}
+}  // namespace
+
+struct dmel_quantizer {
+  int dim, G, Cg, D, nf;
+  int factors[4];
+  int levels[4];
+  FsqConst fk;
+  TensorStore ts;
+  bool ready = false;
+  std::vector<PackedConv> down, up;
+  std::vector<ConvNeXt> down_cx, up_cx;
+  DevBuf w_in, b_in, w_out, b_out;
+};
+
+extern "C" int dmel_quantizer_create(dmel_quantizer** out, int input_dim, int n_groups, const int* levels, int n_levels,
+                                     const int* downsample_factor, int n_factors, int fsq_prebound) {
+  DMEL_CHECK_ARG(out && levels && downsample_factor, "NULL argument");
+  DMEL_CHECK_ARG(n_groups > 0 && input_dim > 0 && input_dim % n_groups == 0, "quantizer: input_dim %d not divisible by groups %d",
+                 input_dim, n_groups);
+  DMEL_CHECK_ARG(n_factors >= 1 && n_factors <= 4, "quantizer: 1..4 downsample stages supported");
+  for (int i = 0; i < n_factors; ++i)
+    if (downsample_factor[i] != 2) {
+      set_error("quantizer: downsample factor %d unsupported (only 2)", downsample_factor[i]);
+      return DMEL_EUNSUPPORTED;
+    }
+  auto* q = new dmel_quantizer();
+  q->dim = input_dim; q->G = n_groups; q->Cg = input_dim / n_groups; q->D = n_levels; q->nf = n_factors;
+  for (int i = 0; i < n_factors; ++i) q->factors[i] = downsample_factor[i];
+  int rc = make_fsq_const(q->fk, levels, n_levels, fsq_prebound);
+  if (rc != DMEL_OK) { delete q; return rc; }
+  for (int i = 0; i < n_levels; ++i) q->levels[i] = levels[i];
+  *out = q;
+  return DMEL_OK;
+}
+extern "C" void dmel_quantizer_destroy(dmel_quantizer* q) { delete q; }
+extern "C" int dmel_quantizer_set_tensor(dmel_quantizer* q, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DMEL_CHECK_ARG(q, "NULL handle");
+  q->ready = false;
+  return q->ts.set(key, data, shape, ndim);
+}
+
+extern "C" int dmel_quantizer_finalize(dmel_quantizer* q) {
+  DMEL_CHECK_ARG(q, "NULL handle");
+  const int C = q->Cg, G = q->G, D = q->D;
+  q->down.clear(); q->up.clear(); q->down_cx.clear(); q->up_cx.clear();
+  q->down.resize(q->nf); q->up.resize(q->nf); q->down_cx.resize(q->nf); q->up_cx.resize(q->nf);
+  for (int i = 0; i < q->nf; ++i) {
+    {  // downsample.{i}.0 = Conv1d(C, C, k=2, stride=2): two 1-tap segments reading x[2s] and x[2s+1]
+      const std::string p = "downsample." + std::to_string(i) + ".0.";
+      const HostTensor* w = q->ts.need(p + "weight", {C, C, 2});
+      const HostTensor* b = q->ts.need(p + "bias", {C});
+      if (!w || !b) return DMEL_EMISSING;
+      PackDesc d;
+      d.mode = EPI_LINEAR; d.nseg = 2; d.C = C;
+      for (int s = 0; s < 2; ++s) { d.seg[s].Cin = C; d.seg[s].tstride = 2; d.seg[s].toff = s; }
+      DMEL_TRY(pack_conv(q->down[i], d, [&](int sg, int row, int ci, int) { return w->v[((size_t)row * C + ci) * 2 + sg]; },
+                         [&](int row) { return b->v[row]; }));
+      DMEL_TRY(build_convnext(q->down_cx[i], q->ts, "downsample." + std::to_string(i) + ".1.", C));
+    }
+    {  // upsample.{i}.0 = ConvTranspose1d(C, C, k=2, stride=2): weight (Cin, Cout, 2); out[2q+ph] = W[:, :, ph]^T x[q]
+      const std::string p = "upsample." + std::to_string(i) + ".0.";
+      const HostTensor* w = q->ts.need(p + "weight", {C, C, 2});
+      const HostTensor* b = q->ts.need(p + "bias", {C});
+      if (!w || !b) return DMEL_EMISSING;
+      PackDesc d;
+      d.mode = EPI_LINEAR; d.nseg = 1; d.C = C; d.phases = 2; d.seg[0].Cin = C;
+      DMEL_TRY(pack_conv(q->up[i], d,
+                         [&](int, int row, int ci, int) { int ph = row / C, co = row % C; return w->v[((size_t)ci * C + co) * 2 + ph]; },
+                         [&](int row) { return b->v[row % C]; }));
+      DMEL_TRY(build_convnext(q->up_cx[i], q->ts, "upsample." + std::to_string(i) + ".1.", C));
+    }
+  }
+  std::vector<float> wi((size_t)G * D * C), bi((size_t)G * D), wo((size_t)G * C * D), bo((size_t)G * C);
+  for (int g = 0; g < G; ++g) {
+    const std::string p = "residual_fsq.rvqs." + std::to_string(g) + ".";
+    const HostTensor* a = q->ts.need(p + "project_in.weight", {D, C});
+    const HostTensor* ab = q->ts.need(p + "project_in.bias", {D});
+    const HostTensor* o = q->ts.need(p + "project_out.weight", {C, D});
+    const HostTensor* ob = q->ts.need(p + "project_out.bias", {C});
+    if (!a || !ab || !o || !ob) return DMEL_EMISSING;
+    std::copy(a->v.begin(), a->v.end(), wi.begin() + (size_t)g * D * C);
+    std::copy(ab->v.begin(), ab->v.end(), bi.begin() + (size_t)g * D);
+    std::copy(o->v.begin(), o->v.end(), wo.begin() + (size_t)g * C * D);
+    std::copy(ob->v.begin(), ob->v.end(), bo.begin() + (size_t)g * C);
+  }
+  DMEL_TRY(upload_vec(q->w_in, wi)); DMEL_TRY(upload_vec(q->b_in, bi));
+  DMEL_TRY(upload_vec(q->w_out, wo)); DMEL_TRY(upload_vec(q->b_out, bo));
+  q->ts.t.clear();
+  q->ready = true;
+  return DMEL_OK;
+}
+
+static size_t quantizer_plan(const dmel_quantizer* q, int B, int64_t Tmax, void* ws, float** a, float** b, float** h1, float** h2) {
+  Arena ar(ws, (size_t)-1);
+  const size_t n = (size_t)B * q->G * q->Cg * Tmax;
+  float* pa = ar.take<float>(n);
+  float* pb = ar.take<float>(n);
+  float* p1 = ar.take<float>(n);
+  float* p2 = ar.take<float>(4 * n);
+  if (a) { *a = pa; *b = pb; *h1 = p1; *h2 = p2; }
+  return align_up(ar.off, 256);
+}
+
+extern "C" size_t dmel_quantizer_workspace_bytes(const dmel_quantizer* q, int B, int64_t T) {
+  if (!q || B <= 0 || T <= 0) return 0;
+  return quantizer_plan(q, B, T, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+extern "C" int dmel_quantizer_encode(const dmel_quantizer* q, const float* z, int32_t* ids, float* prequant, int B, int64_t T,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(q && z && ids && workspace, "quantizer_encode: NULL argument");
+  if (!q->ready) { set_error("quantizer_encode: handle not finalized"); return DMEL_EMISSING; }
+  int64_t Tq = T;
+  for (int i = 0; i < q->nf; ++i) Tq /= 2;
+  DMEL_CHECK_ARG(B > 0 && Tq > 0, "quantizer_encode: sequence too short for the downsampling (T=%lld)", (long long)T);
+  float *pa, *pb, *h1, *h2;
+  const size_t need = quantizer_plan(q, B, T, workspace, &pa, &pb, &h1, &h2);
+  DMEL_CHECK_ARG(workspace_bytes >= need, "quantizer_encode: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const int N = B * q->G, C = q->Cg;
+  const float* cur = z;
+  int64_t Tc = T;
+  float* bufs[2] = {pa, pb};
+  for (int i = 0; i < q->nf; ++i) {  // dowmsample_fsq.py:49-62
+    const int64_t Tn = Tc / 2;
+    float* o = bufs[i & 1];
+    ConvRun r;
+    for (int s = 0; s < 2; ++s) { r.seg[s].x = cur; r.seg[s].bstride = (int64_t)C * Tc; r.seg[s].cstride = Tc; r.seg[s].Tin = Tc; }
+    r.B = N; r.Tcols = Tn; r.y = o; r.y_bs = (int64_t)C * Tn; r.y_cs = Tn; r.Tout = Tn;
+    DMEL_TRY(launch_conv(q->down[i], r, st));
+    DMEL_TRY(run_convnext(q->down_cx[i], o, o, h1, h2, N, C, Tn, st));
+    cur = o;
+    Tc = Tn;
+  }
+  // "(b g) f t -> b (g f) t" is a view; FSQ per group (dowmsample_fsq.py:127-132)
+  return launch_fsq_encode(cur, q->w_in.as<float>(), q->b_in.as<float>(), ids, prequant, q->fk, B, q->G, C, Tc, st);
+}
+
+extern "C" int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids, float* zout, int B, int64_t T4, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(q && ids && zout && workspace, "quantizer_decode: NULL argument");
+  if (!q->ready) { set_error("quantizer_decode: handle not finalized"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(B > 0 && T4 > 0, "quantizer_decode: bad shape");
+  int64_t Tfull = T4;
+  for (int i = 0; i < q->nf; ++i) Tfull *= 2;
+  float *pa, *pb, *h1, *h2;
+  const size_t need = quantizer_plan(q, B, Tfull, workspace, &pa, &pb, &h1, &h2);
+  DMEL_CHECK_ARG(workspace_bytes >= need, "quantizer_decode: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const int N = B * q->G, C = q->Cg;
+  DMEL_TRY(launch_fsq_decode(ids, q->w_out.as<float>(), q->b_out.as<float>(), pa, q->fk, B, q->G, C, T4, st));
+  const float* cur = pa;
+  int64_t Tc = T4;
+  float* bufs[2] = {pb, pa};
+  for (int j = 0; j < q->nf; ++j) {  // dowmsample_fsq.py:64-77 (upsample.{j}: reversed factor order, all factors are 2)
+    const int64_t Tn = Tc * 2;
+    float* o = (j == q->nf - 1) ? zout : bufs[j & 1];
+    ConvRun r = run_1seg(cur, C, Tc, o, C, Tn, N);
+    r.Tcols = Tc; r.out_tstride = 2; r.Tout = Tn;
+    DMEL_TRY(launch_conv(q->up[j], r, st));
+    DMEL_TRY(run_convnext(q->up_cx[j], o, o, h1, h2, N, C, Tn, st));
+    cur = o;
+    Tc = Tn;
+  }
+  return DMEL_OK;
+}
+
+// =====================================================================================================
+// BigVGAN                                          models/modules/bigvgan/bigvgan.py:244-407
+// =====================================================================================================
+namespace {
+struct SnakeP {
+  DevBuf alpha, beta;
+};
+struct AmpBlock {             // AMPBlock1, bigvgan.py:31-147
+  int k;
+  int dil[3];
+  PackedConv c1[3], c2[3];
+  SnakeP act[6];
+};
+struct UpStage {
+  int u, k, Cin, Cout;
+  PackedConv lo, hi;          // phases [0,u/2) with taps d={-1,0}; phases [u/2,u) with taps d={0,+1}
+};
+}  // namespace
+
+struct dmel_bigvgan {
+  dmel_bigvgan_config cfg;
+  TensorStore ts;
+  bool ready = false;
+  PackedConv conv_pre, conv_post;
+  std::vector<UpStage> ups;
+  std::vector<AmpBlock> blocks;
+  SnakeP act_post;
+  float taps[12];
+  int64_t total_up = 1;
+};
+
+extern "C" int dmel_bigvgan_create(dmel_bigvgan** out, const dmel_bigvgan_config* cfg) {
+  DMEL_CHECK_ARG(out && cfg, "NULL argument");
+  DMEL_CHECK_ARG(cfg->num_upsamples >= 1 && cfg->num_upsamples <= 8 && cfg->num_kernels >= 1 && cfg->num_kernels <= 8,
+                 "bigvgan: bad stage/kernel count");
+  DMEL_CHECK_ARG(cfg->num_mels > 0 && cfg->upsample_initial_channel > 0, "bigvgan: bad channel counts");
+  int64_t up = 1;
+  for (int i = 0; i < cfg->num_upsamples; ++i) {
+    const int u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
+    if (k != 2 * u || (u % 2) != 0) {
+      set_error("bigvgan: upsample stage %d (rate %d, kernel %d) unsupported: kernel must be 2*rate with an even rate", i, u, k);
+      return DMEL_EUNSUPPORTED;
+    }
+    DMEL_CHECK_ARG((cfg->upsample_initial_channel >> (i + 1)) > 0, "bigvgan: channel count underflows at stage %d", i);
+    up *= u;
+  }
+  for (int j = 0; j < cfg->num_kernels; ++j) {
+    DMEL_CHECK_ARG(cfg->resblock_kernel_sizes[j] % 2 == 1, "bigvgan: even resblock kernel");
+    for (int l = 0; l < 3; ++l)
+      if ((cfg->resblock_kernel_sizes[j] - 1) * cfg->resblock_dilations[j][l] > 64) {
+        set_error("bigvgan: resblock kernel %d dilation %d exceeds the 64-sample halo", cfg->resblock_kernel_sizes[j],
+                  cfg->resblock_dilations[j][l]);
+        return DMEL_EUNSUPPORTED;
+      }
+  }
+  auto* m = new dmel_bigvgan();
+  m->cfg = *cfg;
+  m->total_up = up;
+  // kaiser_sinc_filter1d(0.25, 0.3, 12) as the reference computes it in fp32 (filter.py:30-62); overridden by any
+  // "*.filter" buffer found in the state dict.
+  static const float kTaps[12] = {0.0020289647f, 0.0093894657f, -0.0255434588f, -0.0576573834f, 0.1285725832f, 0.4432097971f,
+                                  0.4432097971f, 0.1285725832f, -0.0576573834f, -0.0255434588f, 0.0093894657f, 0.0020289647f};
+  std::memcpy(m->taps, kTaps, sizeof(kTaps));
+  *out = m;
+  return DMEL_OK;
+}
+extern "C" void dmel_bigvgan_destroy(dmel_bigvgan* m) { delete m; }
+extern "C" int dmel_bigvgan_set_tensor(dmel_bigvgan* m, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  m->ready = false;
+  return m->ts.set(key, data, shape, ndim);
+}
+
+static int pack_same_conv(PackedConv& pc, const TensorStore& ts, const std::string& prefix, int Cout, int Cin, int k, int dil,
+                          bool has_bias) {
+  std::vector<float> w;
+  if (!ts.conv_weight(prefix, {Cout, Cin, k}, w)) return DMEL_EMISSING;
+  const HostTensor* b = nullptr;
+  if (has_bias) {
+    b = ts.need(prefix + "bias", {Cout});
+    if (!b) return DMEL_EMISSING;
+  }
+  PackDesc d;
+  d.mode = EPI_LINEAR; d.nseg = 1; d.C = Cout;
+  d.seg[0].Cin = Cin; d.seg[0].taps = k; d.seg[0].dil = dil; d.seg[0].pad_left = dil * (k - 1) / 2;  // get_padding, utils.py:57-58
+  return pack_conv(pc, d, [&](int, int row, int ci, int tap) { return w[((size_t)row * Cin + ci) * k + tap]; },
+                   [&](int row) { return b ? b->v[row] : 0.f; });
+}
+
+static int load_snake(SnakeP& s, const TensorStore& ts, const std::string& prefix, int C, bool snake) {
+  const HostTensor* a = ts.need(prefix + "act.alpha", {C});
+  if (!a) return DMEL_EMISSING;
+  DMEL_TRY(upload_vec(s.alpha, a->v));
+  if (!snake) {
+    const HostTensor* b = ts.need(prefix + "act.beta", {C});
+    if (!b) return DMEL_EMISSING;
+    DMEL_TRY(upload_vec(s.beta, b->v));
+  }
+  return DMEL_OK;
+}
+
+extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  const dmel_bigvgan_config& c = m->cfg;
+  const bool snake = c.activation_snake != 0;
+  // anti-alias taps: every Activation1d registers the same two buffers; accept them if present and identical
+  bool have = false;
+  for (auto& kv : m->ts.t) {
+    const std::string& k = kv.first;
+    const bool is_f = k.size() > 7 && k.compare(k.size() - 7, 7, ".filter") == 0;
+    if (!is_f) continue;
+    if (kv.second.numel() != 12) { set_error("bigvgan: filter '%s' is not 12 taps", k.c_str()); return DMEL_EUNSUPPORTED; }
+    if (!have) { std::memcpy(m->taps, kv.second.v.data(), sizeof(m->taps)); have = true; }
+    else if (std::memcmp(m->taps, kv.second.v.data(), sizeof(m->taps)) != 0) {
+      set_error("bigvgan: anti-alias filter '%s' differs from the others (per-activation filters unsupported)", k.c_str());
+      return DMEL_EUNSUPPORTED;
+    }
+  }
+  const int C0 = c.upsample_initial_channel;
+  DMEL_TRY(pack_same_conv(m->conv_pre, m->ts, "conv_pre.", C0, c.num_mels, 7, 1, true));
+  m->ups.clear(); m->blocks.clear();
+  m->ups.resize(c.num_upsamples);
+  m->blocks.resize((size_t)c.num_upsamples * c.num_kernels);
+  int ch = C0;
+  for (int i = 0; i < c.num_upsamples; ++i) {
+    UpStage& us = m->ups[i];
+    us.u = c.upsample_rates[i]; us.k = c.upsample_kernel_sizes[i]; us.Cin = C0 >> i; us.Cout = C0 >> (i + 1);
+    ch = us.Cout;
+    const std::string p = "ups." + std::to_string(i) + ".0.";
+    std::vector<float> w;  // ConvTranspose1d weight (Cin, Cout, k)
+    if (!m->ts.conv_weight(p, {us.Cin, us.Cout, us.k}, w)) return DMEL_EMISSING;
+    const HostTensor* b = m->ts.need(p + "bias", {us.Cout});
+    if (!b) return DMEL_EMISSING;
+    const int u = us.u, k = us.k, hu = u / 2, Co = us.Cout;
+    // y[co, u q + ph] = sum_ci sum_d W[ci, co, ph + u/2 - u d] x[ci, q + d]   (padding (k-u)/2 = u/2)
+    for (int half = 0; half < 2; ++half) {
+      PackDesc d;
+      d.mode = EPI_LINEAR; d.nseg = 1; d.C = Co; d.phases = hu;
+      d.seg[0].Cin = us.Cin; d.seg[0].taps = 2; d.seg[0].dil = 1; d.seg[0].pad_left = half == 0 ? 1 : 0;
+      DMEL_TRY(pack_conv(half == 0 ? us.lo : us.hi, d,
+                         [&](int, int row, int ci, int tap) {
+                           const int ph = row / Co + half * hu, co = row % Co;
+                           const int dd = tap - (half == 0 ? 1 : 0);
+                           const int kk = ph + hu - u * dd;
+                           return (kk >= 0 && kk < k) ? w[((size_t)ci * Co + co) * k + kk] : 0.f;
+                         },
+                         [&](int row) { return b->v[row % Co]; }));
+    }
+    for (int j = 0; j < c.num_kernels; ++j) {
+      AmpBlock& ab = m->blocks[(size_t)i * c.num_kernels + j];
+      ab.k = c.resblock_kernel_sizes[j];
+      const std::string bp = "resblocks." + std::to_string(i * c.num_kernels + j) + ".";
+      for (int l = 0; l < 3; ++l) {
+        ab.dil[l] = c.resblock_dilations[j][l];
+        DMEL_TRY(pack_same_conv(ab.c1[l], m->ts, bp + "convs1." + std::to_string(l) + ".", ch, ch, ab.k, ab.dil[l], true));
+        DMEL_TRY(pack_same_conv(ab.c2[l], m->ts, bp + "convs2." + std::to_string(l) + ".", ch, ch, ab.k, 1, true));
+      }
+      for (int a = 0; a < 6; ++a) DMEL_TRY(load_snake(ab.act[a], m->ts, bp + "activations." + std::to_string(a) + ".", ch, snake));
+    }
+  }
+  DMEL_TRY(load_snake(m->act_post, m->ts, "activation_post.", ch, snake));
+  DMEL_TRY(pack_same_conv(m->conv_post, m->ts, "conv_post.", 1, ch, 7, 1, c.use_bias_at_final != 0));
+  m->ts.t.clear();
+  m->ready = true;
+  return DMEL_OK;
+}
+
+static size_t bigvgan_plan(const dmel_bigvgan* m, int B, int64_t T, void* ws, float* bufs[6]) {
+  const dmel_bigvgan_config& c = m->cfg;
+  size_t mx = (size_t)c.upsample_initial_channel * T;
+  int64_t Tc = T;
+  for (int i = 0; i < c.num_upsamples; ++i) {
+    Tc *= c.upsample_rates[i];
+    mx = std::max(mx, (size_t)(c.upsample_initial_channel >> (i + 1)) * Tc);
+  }
+  Arena a(ws, (size_t)-1);
+  for (int i = 0; i < 6; ++i) {
+    float* p = a.take<float>(mx * B);
+    if (bufs) bufs[i] = p;
+  }
+  return align_up(a.off, 256);
+}
+
+extern "C" size_t dmel_bigvgan_workspace_bytes(const dmel_bigvgan* m, int B, int64_t T) {
+  if (!m || B <= 0 || T <= 0) return 0;
+  return bigvgan_plan(m, B, T, nullptr, nullptr);
+}
+
+extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, float* audio, int B, int64_t T, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(m && mel && audio && workspace, "bigvgan_forward: NULL argument");
+  if (!m->ready) { set_error("bigvgan_forward: handle not finalized"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(B > 0 && T > 0, "bigvgan_forward: bad shape");
+  float* bufs[6];
+  const size_t need = bigvgan_plan(m, B, T, workspace, bufs);
+  DMEL_CHECK_ARG(workspace_bytes >= need, "bigvgan_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+  hipStream_t st = (hipStream_t)stream;
+  const dmel_bigvgan_config& c = m->cfg;
+  const int logscale = c.snake_logscale;
+  float *x = bufs[0], *xu = bufs[1], *xj = bufs[2], *ua = bufs[3], *vb = bufs[4], *xs = bufs[5];
+
+  {  // conv_pre (bigvgan.py:369)
+    ConvRun r = run_1seg(mel, c.num_mels, T, x, c.upsample_initial_channel, T, B);
+    DMEL_TRY(launch_conv(m->conv_pre, r, st));
+  }
+  int64_t Tc = T;
+  int ch = c.upsample_initial_channel;
+  for (int i = 0; i < c.num_upsamples; ++i) {
+    const UpStage& us = m->ups[i];
+    const int64_t Tn = Tc * us.u;
+    for (int half = 0; half < 2; ++half) {  // transposed conv as two phase groups (bigvgan.py:371-374)
+      ConvRun r = run_1seg(x, us.Cin, Tc, xu, us.Cout, Tn, B);
+      r.Tcols = Tc; r.out_tstride = us.u; r.phase_base = half * (us.u / 2); r.Tout = Tn;
+      DMEL_TRY(launch_conv(half == 0 ? us.lo : us.hi, r, st));
+    }
+    ch = us.Cout;
+    Tc = Tn;
+    const int64_t bs = (int64_t)ch * Tc;
+    for (int j = 0; j < c.num_kernels; ++j) {  // AMPBlock1.forward (bigvgan.py:132-141), summed and averaged (:376-382)
+      const AmpBlock& ab = m->blocks[(size_t)i * c.num_kernels + j];
+      const float* xin = xu;
+      for (int l = 0; l < 3; ++l) {
+        DMEL_TRY(launch_aa_snake(xin, ua, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps, logscale, B, ch, Tc, st));
+        ConvRun r1 = run_1seg(ua, ch, Tc, vb, ch, Tc, B);
+        DMEL_TRY(launch_conv(ab.c1[l], r1, st));
+        DMEL_TRY(launch_aa_snake(vb, ua, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps, logscale, B, ch, Tc, st));
+        ConvRun r2 = run_1seg(ua, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
+        r2.res = xin; r2.res_bs = bs; r2.res_cs = Tc;
+        if (l == 2) {
+          r2.accumulate = j > 0;
+          if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
+        }
+        DMEL_TRY(launch_conv(ab.c2[l], r2, st));
+        xin = xj;
+      }
+    }
+    std::swap(x, xs);
+  }
+  // activation_post, conv_post, tanh | clamp (bigvgan.py:385-391)
+  DMEL_TRY(launch_aa_snake(x, ua, m->act_post.alpha.as<float>(), m->act_post.beta.as<float>(), m->taps, logscale, B, ch, Tc, st));
+  ConvRun r = run_1seg(ua, ch, Tc, audio, 1, Tc, B);
+  r.act = c.use_tanh_at_final ? ACT_TANH : ACT_CLAMP1;
+  return launch_conv(m->conv_post, r, st);
+}

@@ -1,0 +1,25 @@
+// Internal launchers shared between the kernel files and the module orchestration (modules.cpp).
+#pragma once
+#include "conv.h"
+
+namespace dmel {
+
+struct FsqConst {
+  int n_levels;
+  int levels[4], half_width[4], basis[4];
+  float half_l[4], offset[4], shift[4];
+  int prebound;
+};
+
+int make_fsq_const(FsqConst& k, const int* levels, int n, int prebound);
+int launch_fsq_encode(const float* z, const float* w_in, const float* b_in, int32_t* ids, float* prequant,
+                      const FsqConst& k, int B, int G, int C, int64_t T4, hipStream_t s);
+int launch_fsq_decode(const int32_t* ids, const float* w_out, const float* b_out, float* z, const FsqConst& k, int B,
+                      int G, int C, int64_t T4, hipStream_t s);
+int launch_dwconv_ln(const float* x, float* y, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                     int N, int C, int64_t T, hipStream_t s);
+int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, int N, int C, int64_t T, hipStream_t s);
+int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host, int logscale,
+                    int B, int C, int64_t T, hipStream_t s);
+
+}  // namespace dmel

@@ -1,0 +1,241 @@
+// Small HBM/launch-bound kernels of the quantiser path (a6-a8 of SURVEY.md section 8): depthwise conv + LayerNorm,
+// FSQ encode / decode, masked copy, mask + quality add.  Their total work is ~0.02 GFLOP per utterance-second.
+#include "ops.h"
+
+namespace dmel {
+
+// ---- ConvNeXt front half: depthwise k7 conv (zero pad 3) then LayerNorm over channels (eps, biased var).
+// firefly.py:386-388 (dwconv, permute, norm).  x, y: (N, C, T).
+constexpr int kDwTile = 32;
+
+__global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ dw_w, const float* __restrict__ dw_b,
+                                                        const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                        int C, int64_t T, float eps) {
+  extern __shared__ float sm[];
+  float* hbuf = sm;                         // [C][kDwTile+1]
+  float* stat = sm + (size_t)C * (kDwTile + 1);  // [2][kDwTile]
+  const int tid = threadIdx.x;
+  const int n = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * kDwTile;
+  const float* xn = x + (int64_t)n * C * T;
+  for (int idx = tid; idx < C * kDwTile; idx += 256) {
+    const int c = idx / kDwTile, j = idx % kDwTile;
+    const int64_t t = t0 + j;
+    float acc = 0.f;
+    if (t < T) {
+      acc = dw_b[c];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int64_t s = t + k - 3;
+        if (s >= 0 && s < T) acc = fmaf(dw_w[c * 7 + k], xn[(int64_t)c * T + s], acc);
+      }
+    }
+    hbuf[c * (kDwTile + 1) + j] = acc;
+  }
+  __syncthreads();
+  if (tid < kDwTile) {
+    float mean = 0.f;
+    for (int c = 0; c < C; ++c) mean += hbuf[c * (kDwTile + 1) + tid];
+    mean /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = hbuf[c * (kDwTile + 1) + tid] - mean;
+      var = fmaf(d, d, var);
+    }
+    var /= (float)C;
+    stat[tid] = mean;
+    stat[kDwTile + tid] = 1.0f / sqrtf(var + eps);
+  }
+  __syncthreads();
+  float* yn = y + (int64_t)n * C * T;
+  for (int idx = tid; idx < C * kDwTile; idx += 256) {
+    const int c = idx / kDwTile, j = idx % kDwTile;
+    const int64_t t = t0 + j;
+    if (t < T) yn[(int64_t)c * T + t] = (hbuf[c * (kDwTile + 1) + j] - stat[j]) * stat[kDwTile + j] * ln_w[c] + ln_b[c];
+  }
+}
+
+int launch_dwconv_ln(const float* x, float* y, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
+                     int N, int C, int64_t T, hipStream_t s) {
+  DMEL_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0, "dwconv_ln: bad shape");
+  const size_t lds = ((size_t)C * (kDwTile + 1) + 2 * kDwTile) * sizeof(float);
+  DMEL_CHECK_ARG(lds <= 64 * 1024, "dwconv_ln: %d channels exceed the LDS tile", C);
+  dim3 grid((unsigned)((T + kDwTile - 1) / kDwTile), (unsigned)N);
+  {
+    ProfScope ps("small", s, 0.0, 8.0 * N * C * (double)T);
+    hipLaunchKernelGGL(dwconv_ln_kernel, grid, dim3(256), lds, s, x, y, dw_w, dw_b, ln_w, ln_b, C, T, 1e-6f);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+// ---- FSQ ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ float fsq_bound(float z, const FsqConst& k, int j) {
+  return tanhf(z + k.shift[j]) * k.half_l[j] - k.offset[j];
+}
+
+// z: (B*G, C, T4) channel-major rows of group g of item b at row b*G+g.  w_in: (G, D, C), b_in: (G, D).
+// ids: (B, G, T4) int32.  prequant (optional): (G, B, T4, D).
+__global__ __launch_bounds__(256) void fsq_encode_kernel(const float* __restrict__ z, const float* __restrict__ w_in,
+                                                         const float* __restrict__ b_in, int32_t* __restrict__ ids,
+                                                         float* __restrict__ prequant, FsqConst k, int B, int G, int C,
+                                                         int64_t T4) {
+  const int64_t total = (int64_t)B * G * T4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t l = i % T4;
+  const int g = (int)((i / T4) % G);
+  const int b = (int)(i / (T4 * G));
+  const float* zr = z + ((int64_t)(b * G + g) * C) * T4 + l;
+  float acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float v = zr[(int64_t)c * T4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < k.n_levels) acc[j] = fmaf(w_in[((int64_t)g * k.n_levels + j) * C + c], v, acc[j]);
+  }
+  int id = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < k.n_levels) {
+      float v = acc[j] + b_in[g * k.n_levels + j];
+      if (k.prebound) v = fsq_bound(v, k, j);
+      v = fsq_bound(v, k, j);
+      if (prequant) prequant[(((int64_t)g * B + b) * T4 + l) * k.n_levels + j] = v;
+      const int q = (int)rintf(v);  // round half to even, as torch.round
+      id += (q + k.half_width[j]) * k.basis[j];
+    }
+  }
+  ids[i] = id;
+}
+
+// ids (B, G, T4) -> z (B*G, C, T4):  code_j = (digit_j - hw_j) / hw_j ; z = W_out code + b_out.  w_out: (G, C, D).
+__global__ __launch_bounds__(256) void fsq_decode_kernel(const int32_t* __restrict__ ids, const float* __restrict__ w_out,
+                                                         const float* __restrict__ b_out, float* __restrict__ z, FsqConst k,
+                                                         int B, int G, int C, int64_t T4) {
+  const int64_t total = (int64_t)B * G * C * T4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t l = i % T4;
+  const int c = (int)((i / T4) % C);
+  const int64_t bg = i / (T4 * C);
+  const int g = (int)(bg % G);
+  const int id = ids[bg * T4 + l];
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (j < k.n_levels) {
+      const int digit = (id / k.basis[j]) % k.levels[j];
+      const float code = ((float)digit - (float)k.half_width[j]) / (float)k.half_width[j];
+      acc = fmaf(w_out[((int64_t)g * C + c) * k.n_levels + j], code, acc);
+    }
+  }
+  z[i] = acc + b_out[g * C + c];
+}
+
+int make_fsq_const(FsqConst& k, const int* levels, int n, int prebound) {
+  DMEL_CHECK_ARG(n >= 1 && n <= 4, "FSQ: 1..4 levels supported, got %d", n);
+  k.n_levels = n;
+  k.prebound = prebound;
+  int basis = 1;
+  for (int j = 0; j < 4; ++j) {
+    if (j < n) {
+      const int L = levels[j];
+      DMEL_CHECK_ARG(L >= 2, "FSQ: level %d < 2", L);
+      k.levels[j] = L;
+      k.half_width[j] = L / 2;
+      k.basis[j] = basis;
+      basis *= L;
+      k.half_l[j] = (float)(L - 1) * 1.001f / 2.0f;   // (levels - 1) * (1 + eps) / 2, eps = 1e-3, in fp32
+      k.offset[j] = (L % 2 == 0) ? 0.5f : 0.0f;
+      k.shift[j] = atanhf(k.offset[j] / k.half_l[j]);
+    } else {
+      k.levels[j] = 1; k.half_width[j] = 1; k.basis[j] = 0; k.half_l[j] = 0; k.offset[j] = 0; k.shift[j] = 0;
+    }
+  }
+  return DMEL_OK;
+}
+
+int launch_fsq_encode(const float* z, const float* w_in, const float* b_in, int32_t* ids, float* prequant,
+                      const FsqConst& k, int B, int G, int C, int64_t T4, hipStream_t s) {
+  const int64_t total = (int64_t)B * G * T4;
+  {
+    ProfScope ps("small", s, 0.0, 4.0 * B * G * C * (double)T4);
+    hipLaunchKernelGGL(fsq_encode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, w_in, b_in, ids,
+                       prequant, k, B, G, C, T4);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+int launch_fsq_decode(const int32_t* ids, const float* w_out, const float* b_out, float* z, const FsqConst& k, int B,
+                      int G, int C, int64_t T4, hipStream_t s) {
+  const int64_t total = (int64_t)B * G * C * T4;
+  {
+    ProfScope ps("small", s, 0.0, 4.0 * (double)total);
+    hipLaunchKernelGGL(fsq_decode_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ids, w_out, b_out, z, k,
+                       B, G, C, T4);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+// ---- y[n,c,t] = x[n,c,t] * (t < len[n / div])   (noise * mask of codec_lit_modules.py:473) ----------
+__global__ __launch_bounds__(256) void masked_copy_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          const int64_t* __restrict__ len, int div, int64_t CT, int64_t T,
+                                                          int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  float v = x[i];
+  if (len) {
+    const int64_t n = i / CT, t = i % T;
+    if (t >= len[n / div]) v = 0.f;
+  }
+  y[i] = v;
+}
+
+int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, int N, int C, int64_t T, hipStream_t s) {
+  const int64_t total = (int64_t)N * C * T;
+  {
+    ProfScope ps("small", s, 0.0, 8.0 * (double)total);
+    hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, len,
+                       div > 0 ? div : 1, (int64_t)C * T, T, total);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+// ---- z = z * mask + (w * value + bias)      codec_lit_modules.py:520-526 --------------------------
+__global__ __launch_bounds__(256) void mask_add_quality_kernel(float* __restrict__ z, const int64_t* __restrict__ len,
+                                                               const float* __restrict__ w, const float* __restrict__ bias,
+                                                               float value, int C, int64_t T, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t t = i % T;
+  const int c = (int)((i / T) % C);
+  const int64_t b = i / (T * C);
+  float v = z[i];
+  if (len && t >= len[b]) v = 0.f;
+  z[i] = v + (w[c] * value + bias[c]);
+}
+
+}  // namespace dmel
+
+extern "C" int dmel_mask_add_quality_f32(float* z, const int64_t* lengths, const float* w, const float* bias, float value,
+                                         int B, int C, int64_t T, void* stream) {
+  using namespace dmel;
+  DMEL_CHECK_ARG(z && w && bias && B > 0 && C > 0 && T > 0, "mask_add_quality: bad argument");
+  const int64_t total = (int64_t)B * C * T;
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope ps("small", s, 0.0, 8.0 * (double)total);
+    hipLaunchKernelGGL(mask_add_quality_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, z, lengths, w,
+                       bias, value, C, T, total);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}

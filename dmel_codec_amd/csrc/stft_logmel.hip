@@ -1,0 +1,349 @@
+// Fused reflect-pad -> hann -> 1024-point real FFT -> |.| -> sparse Slaney mel -> log(clamp) for gfx950.
+//
+// Replaces the six ATen launches of utils/spectrogram.py:58-79 (pad, stft, pow/sum/sqrt, matmul, clamp, log)
+// and never materialises the (B, 513, T) complex spectrum.
+//
+// Mapping: one workgroup = 32 consecutive frames of one clip; each of its 4 waves transforms 8 frames, one
+// frame at a time.  A frame's 1024 real samples are packed as 512 complex points z[n] = x[2n] + i x[2n+1];
+// the 512-point complex FFT is three in-register radix-8 passes (64 lanes x 8 points) with two LDS
+// transposes in between (padded so every ds_read/ds_write is bank-conflict free), then the split-radix
+// style real-FFT recombination, magnitudes into LDS, one lane per mel band walking its triangle (the mel
+// basis is 99 % zeros: each FFT bin feeds at most two bands), log, and a (n_mels x 32) LDS tile so that
+// the (B, n_mels, T) store is made of 128-byte row segments.
+//
+// Algorithmic HBM bytes per frame: hop*4 read + n_mels*4 written.
+#include "common.h"
+
+#include <cmath>
+#include <mutex>
+
+namespace dmel {
+
+constexpr int kNfft = 1024;
+constexpr int kHalf = 512;
+constexpr int kFramesPerWG = 32;
+constexpr int kWaves = 4;
+constexpr int kFramesPerWave = kFramesPerWG / kWaves;
+constexpr int kExch = 8 * 72;  // padded exchange buffer, float2 elements
+constexpr int kMaxMels = 128;
+
+struct cf {
+  float x, y;
+};
+__device__ __forceinline__ cf cadd(cf a, cf b) { return {a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ cf csub(cf a, cf b) { return {a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ cf cmul(cf a, cf b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+__device__ __forceinline__ cf mul_negi(cf a) { return {a.y, -a.x}; }  // a * (-i)
+
+// 4-point forward DFT, natural order in and out.
+__device__ __forceinline__ void dft4(cf c0, cf c1, cf c2, cf c3, cf& y0, cf& y1, cf& y2, cf& y3) {
+  cf d0 = cadd(c0, c2), d1 = csub(c0, c2), d2 = cadd(c1, c3), d3 = mul_negi(csub(c1, c3));
+  y0 = cadd(d0, d2);
+  y1 = cadd(d1, d3);
+  y2 = csub(d0, d2);
+  y3 = csub(d1, d3);
+}
+
+// 8-point forward DFT (decimation in frequency), natural order in and out.
+__device__ __forceinline__ void dft8(cf (&a)[8]) {
+  const float h = 0.70710678118654752440f;
+  cf b0 = cadd(a[0], a[4]), b4 = csub(a[0], a[4]);
+  cf b1 = cadd(a[1], a[5]), t5 = csub(a[1], a[5]);
+  cf b2 = cadd(a[2], a[6]), t6 = csub(a[2], a[6]);
+  cf b3 = cadd(a[3], a[7]), t7 = csub(a[3], a[7]);
+  cf b5 = {(t5.x + t5.y) * h, (t5.y - t5.x) * h};    // * (1 - i)/sqrt2
+  cf b6 = mul_negi(t6);                              // * -i
+  cf b7 = {(t7.y - t7.x) * h, -(t7.x + t7.y) * h};   // * (-1 - i)/sqrt2
+  dft4(b0, b1, b2, b3, a[0], a[2], a[4], a[6]);
+  dft4(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
+}
+
+struct StftTables {
+  const cf* winz;       // [512]   (w[2n], w[2n+1])
+  const cf* tw1;        // [8][64] W512^(k1*lane)
+  const cf* tw2;        // [8][8]  W64^(j1*m2)
+  const cf* twr;        // [257]   W1024^k
+  const int* mel_start; // [n_mels] first FFT bin of the band
+  const int* mel_cnt;   // [n_mels] number of bins
+  const int* mel_ptr;   // [n_mels] offset into mel_w
+  const float* mel_w;   // packed non-zero weights
+};
+
+__device__ __forceinline__ int64_t reflect_index(int64_t s, int64_t L) {
+  if (s < 0) s = -s;
+  if (s >= L) s = 2 * (L - 1) - s;
+  return s;
+}
+
+__global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const float* __restrict__ audio,
+                                                          int64_t row_stride, const int64_t* __restrict__ lengths,
+                                                          float* __restrict__ out, int64_t L, int64_t T, int hop,
+                                                          int pad, int n_mels) {
+  __shared__ cf bufA[kWaves][kExch];
+  __shared__ cf bufB[kWaves][kExch];
+  __shared__ float mag[kWaves][kHalf + 8];
+  __shared__ float tile[kMaxMels][kFramesPerWG + 1];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int b = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * kFramesPerWG;
+  const float* x = audio + (int64_t)b * row_stride;
+
+  // per-lane constants kept in registers across the 8 frames
+  cf wz[8], w1[8], w2[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    wz[j] = tb.winz[64 * j + lane];
+    w1[j] = tb.tw1[64 * j + lane];
+    w2[j] = tb.tw2[8 * j + (lane & 7)];
+  }
+  const int k1 = lane >> 3, l7 = lane & 7;
+  cf* A = bufA[wave];
+  cf* Bx = bufB[wave];
+  float* mg = mag[wave];
+
+  for (int fi = 0; fi < kFramesPerWave; ++fi) {
+    const int f = wave * kFramesPerWave + fi;
+    const int64_t t = t0 + f;
+    const bool valid = t < T;
+    cf r[8];
+    // ---- load + reflect pad + window; lane = n2, reg j = n1, point n = 64 j + lane
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float a0 = 0.f, a1 = 0.f;
+      if (valid) {
+        int64_t s = t * hop + 2 * (64 * j + lane) - pad;
+        int64_t s0 = s, s1 = s + 1;
+        if (s < 0 || s1 >= L) {
+          s0 = reflect_index(s0, L);
+          s1 = reflect_index(s1, L);
+        }
+        a0 = x[s0];
+        a1 = x[s1];
+      }
+      r[j] = {a0 * wz[j].x, a1 * wz[j].y};
+    }
+    // ---- pass 1: DFT over n1, twiddle W512^(k1 n2)
+    dft8(r);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r[j] = cmul(r[j], w1[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) A[j * 72 + lane] = r[j];
+    __syncthreads();
+    // lane = (k1, m2); reg m1 <- A[k1][8 m1 + m2]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = A[k1 * 72 + 8 * j + l7];
+    // ---- pass 2: DFT over m1, twiddle W64^(j1 m2)
+    dft8(r);
+#pragma unroll
+    for (int j = 1; j < 8; ++j) r[j] = cmul(r[j], w2[j]);
+    // transpose inside each 8-lane group: writer (k1, m2) reg j1 -> reader (k1, j1) reg m2
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Bx[k1 * 72 + j + 9 * l7] = r[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = Bx[k1 * 72 + l7 + 9 * j];
+    // ---- pass 3: DFT over m2 -> Z[k1 + 8 j1 + 64 j2]; store in natural order, one pad slot per 8
+    dft8(r);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) A[k1 + 9 * l7 + 72 * j] = r[j];
+    __syncthreads();
+    // ---- real-FFT recombination + magnitude; lane handles k = lane + 64 j and its mirror 512 - k
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      const int k = lane + 64 * j;
+      if (j < 4 || lane == 0) {
+        const int km = (kHalf - k) & (kHalf - 1);
+        cf zk = A[k + (k >> 3)], zm = A[km + (km >> 3)];
+        cf e = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
+        cf o = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
+        cf wo = cmul(tb.twr[k], o);
+        cf xk = cadd(e, wo), xm = csub(e, wo);
+        mg[k] = sqrtf(xk.x * xk.x + xk.y * xk.y + 1e-9f);
+        mg[kHalf - k] = sqrtf(xm.x * xm.x + xm.y * xm.y + 1e-9f);
+      }
+    }
+    __syncthreads();
+    // ---- mel: one lane per band, ascending-bin fma chain over the band's triangle
+    for (int m = lane; m < n_mels; m += 64) {
+      const int st = tb.mel_start[m], cnt = tb.mel_cnt[m];
+      const float* w = tb.mel_w + tb.mel_ptr[m];
+      float acc = 0.f;
+      for (int i = 0; i < cnt; ++i) acc = fmaf(w[i], mg[st + i], acc);
+      tile[m][f] = logf(fmaxf(acc, 1e-5f));
+    }
+    // (the next frame's writes to mg/A/Bx are each separated from these reads by a barrier above)
+  }
+  __syncthreads();
+  const int64_t n_valid = lengths ? lengths[b] / hop : T;
+  float* o = out + (int64_t)b * n_mels * T;
+  for (int idx = tid; idx < n_mels * kFramesPerWG; idx += 256) {
+    const int m = idx / kFramesPerWG, f = idx % kFramesPerWG;
+    const int64_t t = t0 + f;
+    if (t < T) o[(int64_t)m * T + t] = (t < n_valid) ? tile[m][f] : 0.f;
+  }
+}
+
+}  // namespace dmel
+
+using namespace dmel;
+
+struct dmel_stft_plan {
+  int sample_rate, n_fft, win_length, hop, n_mels, pad;
+  double f_min, f_max;
+  std::vector<float> basis;  // dense (n_mels, 513), host copy
+  DevBuf winz, tw1, tw2, twr, mel_start, mel_cnt, mel_ptr, mel_w;
+};
+
+namespace {
+
+// Slaney mel scale (librosa filters.mel, htk=False): linear below 1 kHz, log above.
+const double kFsp = 200.0 / 3.0, kMinLogHz = 1000.0, kMinLogMel = kMinLogHz / kFsp;
+double hz_to_mel(double f) {
+  static const double logstep = std::log(6.4) / 27.0;
+  return f >= kMinLogHz ? kMinLogMel + std::log(f / kMinLogHz) / logstep : f / kFsp;
+}
+double mel_to_hz(double m) {
+  static const double logstep = std::log(6.4) / 27.0;
+  return m >= kMinLogMel ? kMinLogHz * std::exp(logstep * (m - kMinLogMel)) : kFsp * m;
+}
+
+void build_mel_basis(int sr, int n_fft, int n_mels, double fmin, double fmax, std::vector<float>& w) {
+  const int nb = n_fft / 2 + 1;
+  w.assign((size_t)n_mels * nb, 0.f);
+  std::vector<double> mel_f(n_mels + 2);
+  const double m_lo = hz_to_mel(fmin), m_hi = hz_to_mel(fmax);
+  for (int i = 0; i < n_mels + 2; ++i) {
+    // numpy.linspace: start + i*step, last point exact
+    double step = (m_hi - m_lo) / (n_mels + 1);
+    double m = (i == n_mels + 1) ? m_hi : m_lo + i * step;
+    mel_f[i] = mel_to_hz(m);
+  }
+  for (int i = 0; i < n_mels; ++i) {
+    const double fd0 = mel_f[i + 1] - mel_f[i], fd1 = mel_f[i + 2] - mel_f[i + 1];
+    const double enorm = 2.0 / (mel_f[i + 2] - mel_f[i]);
+    for (int k = 0; k < nb; ++k) {
+      const double fk = (double)k * sr / n_fft;
+      const double lower = -(mel_f[i] - fk) / fd0, upper = (mel_f[i + 2] - fk) / fd1;
+      const double v = std::fmax(0.0, std::fmin(lower, upper));
+      const float v32 = (float)v;                       // librosa stores float32, then scales
+      w[(size_t)i * nb + k] = (float)((double)v32 * enorm);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int dmel_stft_plan_create(dmel_stft_plan** out, int sample_rate, int n_fft, int win_length, int hop_length,
+                                     int n_mels, double f_min, double f_max, const float* window_host) {
+  DMEL_CHECK_ARG(out != nullptr, "plan out pointer is NULL");
+  *out = nullptr;
+  if (n_fft != kNfft) {
+    set_error("stft_logmel: n_fft=%d unsupported (gfx950 kernel is specialised for n_fft=1024)", n_fft);
+    return DMEL_EUNSUPPORTED;
+  }
+  DMEL_CHECK_ARG(win_length > 0 && win_length <= n_fft, "win_length %d out of range", win_length);
+  DMEL_CHECK_ARG(hop_length > 0 && hop_length <= n_fft && (n_fft - hop_length) % 2 == 0,
+                 "hop_length %d unsupported (need 0 < hop <= n_fft, n_fft-hop even)", hop_length);
+  DMEL_CHECK_ARG(n_mels > 0 && n_mels <= kMaxMels, "n_mels %d out of range (1..128)", n_mels);
+  DMEL_CHECK_ARG(sample_rate > 0, "bad sample_rate");
+  if (f_max <= 0) f_max = sample_rate / 2.0;
+  auto* p = new dmel_stft_plan();
+  p->sample_rate = sample_rate; p->n_fft = n_fft; p->win_length = win_length; p->hop = hop_length;
+  p->n_mels = n_mels; p->pad = (n_fft - hop_length) / 2; p->f_min = f_min; p->f_max = f_max;
+
+  // window (zero-padded to n_fft, centred, as torch.stft does for win_length < n_fft)
+  std::vector<float> win(n_fft, 0.f);
+  const int woff = (n_fft - win_length) / 2;
+  for (int n = 0; n < win_length; ++n) {
+    win[woff + n] = window_host ? window_host[n]
+                                : (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)win_length));
+  }
+  std::vector<cf> winz(kHalf), tw1(8 * 64), tw2(64), twr(257);
+  for (int n = 0; n < kHalf; ++n) winz[n] = {win[2 * n], win[2 * n + 1]};
+  for (int k = 0; k < 8; ++k)
+    for (int l = 0; l < 64; ++l) {
+      double a = -2.0 * M_PI * (double)(k * l) / 512.0;
+      tw1[k * 64 + l] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+  for (int j = 0; j < 8; ++j)
+    for (int m = 0; m < 8; ++m) {
+      double a = -2.0 * M_PI * (double)(j * m) / 64.0;
+      tw2[j * 8 + m] = {(float)std::cos(a), (float)std::sin(a)};
+    }
+  for (int k = 0; k <= 256; ++k) {
+    double a = -2.0 * M_PI * (double)k / 1024.0;
+    twr[k] = {(float)std::cos(a), (float)std::sin(a)};
+  }
+  build_mel_basis(sample_rate, n_fft, n_mels, f_min, f_max, p->basis);
+  const int nb = n_fft / 2 + 1;
+  std::vector<int> st(n_mels), cnt(n_mels), ptr(n_mels);
+  std::vector<float> packed;
+  for (int m = 0; m < n_mels; ++m) {
+    int lo = nb, hi = -1;
+    for (int k = 0; k < nb; ++k)
+      if (p->basis[(size_t)m * nb + k] != 0.f) { lo = std::min(lo, k); hi = std::max(hi, k); }
+    st[m] = hi < 0 ? 0 : lo;
+    cnt[m] = hi < 0 ? 0 : hi - lo + 1;
+    ptr[m] = (int)packed.size();
+    for (int k = 0; k < cnt[m]; ++k) packed.push_back(p->basis[(size_t)m * nb + st[m] + k]);
+  }
+  if (packed.empty()) packed.push_back(0.f);
+  int rc = DMEL_OK;
+  if ((rc = p->winz.upload(winz.data(), winz.size() * sizeof(cf))) || (rc = p->tw1.upload(tw1.data(), tw1.size() * sizeof(cf))) ||
+      (rc = p->tw2.upload(tw2.data(), tw2.size() * sizeof(cf))) || (rc = p->twr.upload(twr.data(), twr.size() * sizeof(cf))) ||
+      (rc = p->mel_start.upload(st.data(), st.size() * sizeof(int))) || (rc = p->mel_cnt.upload(cnt.data(), cnt.size() * sizeof(int))) ||
+      (rc = p->mel_ptr.upload(ptr.data(), ptr.size() * sizeof(int))) || (rc = p->mel_w.upload(packed.data(), packed.size() * sizeof(float)))) {
+    delete p;
+    return rc;
+  }
+  *out = p;
+  return DMEL_OK;
+}
+
+extern "C" int dmel_mel_basis_host(int sample_rate, int n_fft, int n_mels, double f_min, double f_max, float* basis_host) {
+  DMEL_CHECK_ARG(basis_host && sample_rate > 0 && n_fft > 0 && n_mels > 0, "mel_basis_host: bad argument");
+  if (f_max <= 0) f_max = sample_rate / 2.0;
+  std::vector<float> w;
+  build_mel_basis(sample_rate, n_fft, n_mels, f_min, f_max, w);
+  std::memcpy(basis_host, w.data(), w.size() * sizeof(float));
+  return DMEL_OK;
+}
+
+extern "C" void dmel_stft_plan_destroy(dmel_stft_plan* p) { delete p; }
+
+extern "C" int dmel_stft_plan_mel_basis(const dmel_stft_plan* p, float* basis_host) {
+  DMEL_CHECK_ARG(p && basis_host, "NULL argument");
+  std::memcpy(basis_host, p->basis.data(), p->basis.size() * sizeof(float));
+  return DMEL_OK;
+}
+
+extern "C" int64_t dmel_stft_num_frames(const dmel_stft_plan* p, int64_t L) {
+  if (!p) return -1;
+  int64_t padded = L + 2 * p->pad;
+  if (padded < p->n_fft) return 0;
+  return 1 + (padded - p->n_fft) / p->hop;
+}
+
+extern "C" int dmel_stft_logmel_f32(const dmel_stft_plan* p, const float* audio, int64_t row_stride, const int64_t* lengths,
+                                    float* out, int B, int64_t L, void* stream) {
+  DMEL_CHECK_ARG(p && audio && out, "NULL argument");
+  DMEL_CHECK_ARG(B > 0 && B <= 65535, "batch %d out of range", B);
+  DMEL_CHECK_ARG(L > p->pad, "clip length %lld must exceed the reflect pad %d", (long long)L, p->pad);
+  DMEL_CHECK_ARG(row_stride >= L, "row stride smaller than L");
+  const int64_t T = dmel_stft_num_frames(p, L);
+  DMEL_CHECK_ARG(T > 0, "clip too short for one frame");
+  StftTables tb{p->winz.as<cf>(), p->tw1.as<cf>(), p->tw2.as<cf>(), p->twr.as<cf>(), p->mel_start.as<int>(),
+                p->mel_cnt.as<int>(), p->mel_ptr.as<int>(), p->mel_w.as<float>()};
+  dim3 grid((unsigned)((T + kFramesPerWG - 1) / kFramesPerWG), (unsigned)B);
+  hipStream_t s = (hipStream_t)stream;
+  {
+    ProfScope ps("stft_logmel", s, 0.0, (double)B * (4.0 * (double)L + 4.0 * p->n_mels * (double)T));
+    hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(256), 0, s, tb, audio, row_stride, lengths, out, L, T, p->hop,
+                       p->pad, p->n_mels);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}

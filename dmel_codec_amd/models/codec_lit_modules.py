@@ -1,0 +1,144 @@
+"""VQGAN codec: encode() / decode() on the MI355X.  Drop-in for the inference surface of
+dmel_codec/models/codec_lit_modules.py (reference): same ctor kwargs, attribute names, state-dict prefixes
+(`encoder.*`, `quantizer.*`, `decoder.*`, `quality_projection.*`, `vocoder.*`) and method signatures
+(:462-531).  Lightning is not a dependency: this is a plain nn.Module (the Lightning shell -- optimisers,
+training_step, logging -- is SURVEY.md 8f rank 1, not built yet).
+
+Every tensor op of the path is a native HIP launch; torch only owns the memory and the stream."""
+from __future__ import annotations
+
+import math
+from pathlib import Path
+from typing import Callable, Optional
+
+import torch
+from torch import nn
+
+from .. import _lib
+from ..utils.spectrogram import LogMelSpectrogram
+from ..utils.utils import sequence_mask
+from .modules.bigvgan.bigvgan import BigVGAN
+from .modules.dowmsample_fsq import DownsampleFiniteScalarQuantize
+from .modules.wavenet import WaveNet
+
+
+class VQGAN(nn.Module):
+    def __init__(self, encoder: WaveNet, quantizer: DownsampleFiniteScalarQuantize, vocoder: Optional[BigVGAN],
+                 encode_mel_transform: LogMelSpectrogram, gt_mel_transform: Optional[LogMelSpectrogram] = None,
+                 optimizer: Callable | None = None, lr_scheduler: Callable | None = None, discriminator=None,
+                 decoder: WaveNet | None = None, weight_adv: float = 1.0, weight_vq: float = 1.0,
+                 weight_mel: float = 1.0, sampling_rate: int = 44100, freeze_encoder: bool = False,
+                 dmel_groups: int = 0, quanlity_linear: int = 768, dtype: torch.dtype | str = "bfloat16",
+                 accumulate_grad: int = 1, load_vocoder_ckpt: bool = True):
+        super().__init__()
+        # codec_lit_modules.py:52-56.  The native path computes in fp32 (the reference's codec-training dtype,
+        # dMel_example.yaml:47); a bf16 request (LM configs) is honoured at the API boundary only.
+        self.encode_dtype = getattr(torch, dtype) if isinstance(dtype, str) else dtype
+        self.optimizer_builder, self.lr_scheduler_builder = optimizer, lr_scheduler
+        self.encoder, self.quantizer = encoder, quantizer
+        # codec_lit_modules.py:66-84: the reference keeps vocoder/decoder/discriminator only when the vocoder
+        # checkpoint exists on disk.  load_vocoder_ckpt=False (extension) keeps randomly initialised modules, which
+        # is what the parity tests and the synthetic benchmark need (no weights ship with the reference).
+        if vocoder is not None and load_vocoder_ckpt and vocoder.ckpt_path and Path(vocoder.ckpt_path).exists():
+            vocoder.load_state_dict(torch.load(vocoder.ckpt_path, map_location="cpu")["generator"], strict=True)
+            keep = True
+        else:
+            keep = vocoder is not None and not load_vocoder_ckpt
+        if keep:
+            self.vocoder = vocoder.eval()
+            for p in self.vocoder.parameters():
+                p.requires_grad = False
+            self.decoder, self.discriminator = decoder, discriminator
+        else:
+            self.vocoder, self.decoder, self.discriminator = None, None, None
+        self.encode_mel_transform = encode_mel_transform
+        self.gt_mel_transform = gt_mel_transform
+        self.quality_projection = nn.Linear(1, quanlity_linear)   # codec_lit_modules.py:89
+        self.weight_adv, self.weight_vq, self.weight_mel = weight_adv, weight_vq, weight_mel
+        self.sampling_rate = sampling_rate
+        self.strict_loading = False
+        if freeze_encoder:
+            for p in list(self.encoder.parameters()) + list(self.quantizer.parameters()):
+                p.requires_grad = False
+        self.dmel_groups = dmel_groups
+        self.accumulate_grad = accumulate_grad
+        if dmel_groups <= 0:
+            raise NotImplementedError("only the dMel layout (dmel_groups > 0) works in the reference (SURVEY.md App. C)")
+
+    @property
+    def device(self) -> torch.device:
+        return self.quality_projection.weight.device
+
+    def expand_mask(self, mask_matrix):
+        return mask_matrix.repeat_interleave(self.dmel_groups, dim=0)
+
+    @staticmethod
+    def _lengths(v: torch.Tensor) -> torch.Tensor:
+        return v.squeeze(0) if v.ndim == 2 else v      # collate emits (1, B): utils/utils.py:50-51
+
+    # ------------------------------------------------------------------------------ encode side
+    @torch.no_grad()
+    def encode_unquantized(self, audios, audio_lengths):
+        """codec_lit_modules.py:486-513 -> features (B*G, C, T), mel_lengths (B,)"""
+        audios = audios.float()
+        audio_lengths = self._lengths(audio_lengths)
+        hop = self.encode_mel_transform.hop_length
+        mel_lengths = audio_lengths // hop
+        # mels * mask fused into the STFT kernel's store; "(B, n_mels, T) -> (B*G, n_mels/G, T)" is a view
+        mels = self.encode_mel_transform(audios, lengths=audio_lengths)
+        B, n_mels, T = mels.shape
+        x = mels.view(B * self.dmel_groups, n_mels // self.dmel_groups, T)
+        ml = mel_lengths.to(mels.device)
+        feats = self.encoder(x, out_lengths=ml, group_repeat=self.dmel_groups)
+        return feats.to(self.encode_dtype), mel_lengths
+
+    @torch.no_grad()
+    def get_indices_from_unquantized_features(self, unquantized_features, mel_lengths):
+        """codec_lit_modules.py:529-531"""
+        indices_lengths = mel_lengths // math.prod(self.quantizer.downsample_factor)
+        return self.quantizer.encode(unquantized_features), indices_lengths
+
+    @torch.no_grad()
+    def encode(self, audios, audio_lengths):
+        """codec_lit_modules.py:462-466 -> indices (B, G, T4) int32, indices_lengths (B,)"""
+        feats, mel_lengths = self.encode_unquantized(audios, audio_lengths)
+        return self.get_indices_from_unquantized_features(feats, mel_lengths)
+
+    # ------------------------------------------------------------------------------ decode side
+    @torch.no_grad()
+    def get_quantized_features_from_indices(self, indices, feature_lengths):
+        """codec_lit_modules.py:515-527 -> z (B, G*C, 4*T4), mask (B, 1, 4*T4)"""
+        feature_lengths = self._lengths(feature_lengths)
+        factor = math.prod(self.quantizer.downsample_factor)
+        _lib.require_cuda(indices, "indices")
+        z = self.quantizer.decode(indices)
+        B, Cc, T = z.shape
+        lens = (feature_lengths.to(device=z.device, dtype=torch.int64) * factor).contiguous()
+        w = self.quality_projection.weight.detach().reshape(-1).to(z.device, torch.float32).contiguous()
+        b = self.quality_projection.bias.detach().to(z.device, torch.float32).contiguous()
+        with torch.cuda.device(z.device):
+            _lib.check(_lib.lib().dmel_mask_add_quality_f32(z.data_ptr(), lens.data_ptr(), w.data_ptr(), b.data_ptr(), 2.0,
+                                                            B, Cc, T, _lib.stream_ptr()), "mask_add_quality")
+        mask = sequence_mask(lens, T)[:, None, :].to(self.encode_dtype)
+        return z, mask
+
+    @torch.no_grad()
+    def decode(self, indices, feature_lengths, return_audios=False, noise: Optional[torch.Tensor] = None):
+        """codec_lit_modules.py:468-484.  noise (extension): the Gaussian decoder input the reference draws with
+        torch.randn_like (:473); pass it for reproducible / parity runs."""
+        if self.decoder is None:
+            raise ValueError("Decoder is not loaded")
+        feature_lengths = self._lengths(feature_lengths)
+        factor = math.prod(self.quantizer.downsample_factor)
+        z, _ = self.get_quantized_features_from_indices(indices, feature_lengths)
+        if noise is None:
+            noise = torch.randn_like(z)
+        elif noise.shape != z.shape:
+            raise ValueError(f"noise must have shape {tuple(z.shape)}")
+        lens = (feature_lengths.to(device=z.device, dtype=torch.int64) * factor).contiguous()
+        gen_mel = self.decoder(noise.to(z.device), condition=z, in_lengths=lens, out_lengths=lens)
+        if return_audios:
+            if self.vocoder is None:
+                raise ValueError("Vocoder is not loaded")
+            return self.vocoder(gen_mel), gen_mel
+        return gen_mel

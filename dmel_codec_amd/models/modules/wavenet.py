@@ -1,0 +1,147 @@
+"""WaveNet on the MI355X.  Drop-in for dmel_codec/models/modules/wavenet.py (reference): same class names, ctor
+kwargs, parameter names (state-dict keys) and initialisation; forward runs the fused HIP path
+(csrc/modules.hip: dmel_wavenet_forward) -- one implicit-GEMM launch per gated conv and one per output projection.
+Inference only (no autograd through the native call)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+from torch import nn
+
+from ... import _lib
+from ._native import NativeModule
+
+
+class LinearNorm(nn.Module):
+    """wavenet.py:31-44 (parameter container; only used by the unused diffusion branch)."""
+
+    def __init__(self, in_features, out_features, bias=False):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias)
+        nn.init.xavier_uniform_(self.linear.weight)
+        if bias:
+            nn.init.constant_(self.linear.bias, 0.0)
+
+
+class ConvNorm(nn.Module):
+    """wavenet.py:47-81 (parameter container)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=1, stride=1, padding=None, dilation=1, bias=True,
+                 w_init_gain="linear"):
+        super().__init__()
+        if padding is None:
+            assert kernel_size % 2 == 1
+            padding = int(dilation * (kernel_size - 1) / 2)
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                              dilation=dilation, bias=bias)
+        nn.init.kaiming_normal_(self.conv.weight)
+
+
+class ResidualBlock(nn.Module):
+    """wavenet.py:84-135 (parameter container; the arithmetic of :116-135 runs inside dmel_wavenet_forward)."""
+
+    def __init__(self, residual_channels, use_linear_bias=False, dilation=1, condition_channels=None):
+        super().__init__()
+        self.conv_layer = ConvNorm(residual_channels, 2 * residual_channels, kernel_size=3, stride=1,
+                                   padding=dilation, dilation=dilation)
+        if condition_channels is not None:
+            # dead parameters in the reference too (never used when diffusion_step is None, wavenet.py:119-121)
+            self.diffusion_projection = LinearNorm(residual_channels, residual_channels, use_linear_bias)
+            self.condition_projection = ConvNorm(condition_channels, 2 * residual_channels, kernel_size=1)
+        self.output_projection = ConvNorm(residual_channels, 2 * residual_channels, kernel_size=1)
+
+
+class WaveNet(NativeModule):
+    """wavenet.py:138-225."""
+
+    _destroy_symbol = "dmel_wavenet_destroy"
+    _set_symbol = "dmel_wavenet_set_tensor"
+    _finalize_symbol = "dmel_wavenet_finalize"
+
+    def __init__(self, input_channels: Optional[int] = None, output_channels: Optional[int] = None,
+                 residual_channels: int = 512, residual_layers: int = 20, dilation_cycle: Optional[int] = 4,
+                 is_diffusion: bool = False, condition_channels: Optional[int] = None):
+        super().__init__()
+        if is_diffusion:
+            raise NotImplementedError("is_diffusion=True is never set by a reference config and is not built")
+        self.input_projection = None
+        if input_channels is not None and input_channels != residual_channels:
+            self.input_projection = ConvNorm(input_channels, residual_channels, kernel_size=1)
+        if input_channels is None:
+            input_channels = residual_channels
+        self.input_channels = input_channels
+        self.residual_channels = residual_channels
+        self.dilation_cycle = dilation_cycle
+        self.condition_channels = condition_channels
+        self.residual_layers = nn.ModuleList([
+            ResidualBlock(residual_channels=residual_channels, use_linear_bias=False,
+                          dilation=2 ** (i % dilation_cycle) if dilation_cycle else 1,
+                          condition_channels=condition_channels)
+            for i in range(residual_layers)])
+        self.skip_projection = ConvNorm(residual_channels, residual_channels, kernel_size=1)
+        self.output_projection = None
+        self.output_channels = residual_channels
+        if output_channels is not None and output_channels != residual_channels:
+            self.output_projection = ConvNorm(residual_channels, output_channels, kernel_size=1)
+            self.output_channels = output_channels
+        self.apply(self._init_weights)
+
+    def _init_weights(self, m):
+        if isinstance(m, (nn.Conv1d, nn.Linear)):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if getattr(m, "bias", None) is not None:
+                nn.init.constant_(m.bias, 0)
+
+    def _native_state(self) -> dict:
+        return {k: v for k, v in self.state_dict().items() if "diffusion_projection" not in k}
+
+    def _create_native(self) -> int:
+        h = C.c_void_p()
+        _lib.check(_lib.lib().dmel_wavenet_create(C.byref(h), self.input_channels, self.output_channels,
+                                                  self.residual_channels, len(self.residual_layers),
+                                                  self.dilation_cycle or 0, self.condition_channels or 0),
+                   "wavenet_create")
+        return h.value
+
+    @torch.no_grad()
+    def forward(self, x, t=None, condition=None, in_lengths=None, out_lengths=None, group_repeat: int = 1):
+        """x (N, Cin, T), condition (N, Ccond, T) -> (N, Cout, T).
+        Extensions (optional): in_lengths / out_lengths (N // group_repeat,) int64 fuse the `x * mask` in front of
+        and behind the stack (codec_lit_modules.py:471-477, 505-506)."""
+        if t is not None:
+            raise NotImplementedError("diffusion step input is not built (never used by the codec path)")
+        _lib.require_cuda(x, "x")
+        if x.ndim != 3 or x.shape[1] != self.input_channels:
+            raise ValueError(f"expected (N, {self.input_channels}, T), got {tuple(x.shape)}")
+        x = x.float().contiguous()
+        N, _, T = x.shape
+        if (condition is not None) != bool(self.condition_channels):
+            raise ValueError("condition tensor does not match condition_channels")
+        if condition is not None:
+            _lib.require_cuda(condition, "condition")
+            if condition.shape != (N, self.condition_channels, T):
+                raise ValueError(f"condition must be {(N, self.condition_channels, T)}, got {tuple(condition.shape)}")
+            condition = condition.float().contiguous()
+        dev = x.device
+
+        def lens(v):
+            if v is None:
+                return None
+            v = v.reshape(-1).to(device=dev, dtype=torch.int64).contiguous()
+            if v.numel() * group_repeat != N:
+                raise ValueError("lengths do not match the batch")
+            return v
+
+        il, ol = lens(in_lengths), lens(out_lengths)
+        L = _lib.lib()
+        h = self.native()
+        y = torch.empty(N, self.output_channels, T, dtype=torch.float32, device=dev)
+        nbytes = L.dmel_wavenet_workspace_bytes(h, N, T)
+        ws = self._ws.get(nbytes, dev)
+        with torch.cuda.device(dev):
+            _lib.check(L.dmel_wavenet_forward(h, x.data_ptr(), _lib.ptr(condition), y.data_ptr(), N, T, _lib.ptr(il),
+                                              _lib.ptr(ol), group_repeat, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                       "wavenet_forward")
+        return y

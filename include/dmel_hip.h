@@ -1,0 +1,166 @@
+/*
+ * dmel_hip.h -- C ABI of libdmel_hip.so, the MI355X (gfx950) native dMel codec hot path.
+ *
+ * Drop-in boundary: the reference's plugin surface is its Python module API
+ * (Hydra `_target_` strings); its one native ABI is `fwd_cuda` of the anti-alias activation
+ * (models/modules/bigvgan/alias_free_activation/cuda/anti_alias_activation_cuda.cu:212,
+ *  anti_alias_activation.cpp:21-23), a C++ (torch::Tensor) ABI.  This header is what a binding of the
+ * reference's path binds instead: plain pointers, sizes and an opaque stream -- no torch types.
+ *
+ * Conventions
+ *   - every `const float*`/`float*` tensor argument is DEVICE memory unless the name ends in `_host`;
+ *   - the caller owns every buffer, including the workspace (size from the matching *_workspace_bytes);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all launches are asynchronous on
+ *     it and the library never synchronises inside a forward call;
+ *   - return value: 0 = ok, <0 = invalid argument / unsupported configuration, >0 = hipError_t;
+ *     dmel_last_error() returns a thread-local description of the last failure;
+ *   - layouts are the reference's: activations (B, C, T) fp32 with T contiguous, audio (B, L) fp32,
+ *     token ids (B, G*R, T4) int32.
+ */
+#ifndef DMEL_HIP_H
+#define DMEL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DMEL_OK 0
+#define DMEL_EINVAL (-1)
+#define DMEL_EUNSUPPORTED (-2)
+#define DMEL_EMISSING (-3)
+
+const char* dmel_last_error(void);
+/* ABI version of this header; bumped on any signature change. */
+int dmel_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * STFT -> magnitude -> mel -> log            replaces utils/spectrogram.py:41-81 (LinearSpectrogram.forward)
+ * The plan caches the hann window, FFT twiddles and the sparse Slaney mel basis on the device, as the
+ * reference caches mel basis + window per (config, device) (utils/spectrogram.py:43-56).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dmel_stft_plan dmel_stft_plan;
+
+/* f_max <= 0 means sample_rate/2 (librosa default when fmax=None).  window_host: win_length floats or
+ * NULL for the periodic hann window torch.hann_window(win_length) (spectrogram.py:53).
+ * Supported: n_fft == 1024, win_length <= n_fft, (n_fft - hop_length) even, n_mels <= 128. */
+int dmel_stft_plan_create(dmel_stft_plan** plan, int sample_rate, int n_fft, int win_length, int hop_length,
+                          int n_mels, double f_min, double f_max, const float* window_host);
+void dmel_stft_plan_destroy(dmel_stft_plan* plan);
+/* Host-only helper (no device needed): the dense (n_mels, n_fft/2+1) Slaney mel basis, librosa 0.10.2
+ * filters.mel(htk=False, norm="slaney") semantics (call site utils/spectrogram.py:45-52).  f_max <= 0: sr/2. */
+int dmel_mel_basis_host(int sample_rate, int n_fft, int n_mels, double f_min, double f_max, float* basis_host);
+/* Copy the dense (n_mels, n_fft/2+1) mel basis the plan was built from to host memory. */
+int dmel_stft_plan_mel_basis(const dmel_stft_plan* plan, float* basis_host);
+/* Number of frames for an L-sample clip: 1 + (L + 2*pad - n_fft) / hop with pad = (n_fft-hop)/2. */
+int64_t dmel_stft_num_frames(const dmel_stft_plan* plan, int64_t L);
+/* audio (B, L) with row stride audio_row_stride (elements).  out (B, n_mels, T).
+ * lengths: NULL, or B int64 sample counts: frames t >= lengths[b]/hop are written as 0 (the `mels * mask`
+ * of codec_lit_modules.py:492-506 fused in). */
+int dmel_stft_logmel_f32(const dmel_stft_plan* plan, const float* audio, int64_t audio_row_stride,
+                         const int64_t* lengths, float* out, int B, int64_t L, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Anti-aliased Snake / SnakeBeta           replaces fwd_cuda (anti_alias_activation_cuda.cu:212-246) and the
+ * torch Activation1d (alias_free_activation/torch/act.py:25-30): x2 up (12-tap kaiser-sinc, replicate pad)
+ * -> x + 1/(b+1e-9) sin^2(a x) -> x2 down (12 taps, replicate pad 5/6).  alpha/beta: (C) as stored in the
+ * state dict; logscale != 0 applies exp() as the reference does.  beta == NULL means Snake (beta := alpha).
+ * filter_host: 12 taps used for both directions (the reference registers the same filter twice).
+ * ---------------------------------------------------------------------------------------------- */
+int dmel_aa_snake_f32(const float* x, float* y, const float* alpha, const float* beta, const float* filter12_host,
+                      int logscale, int B, int C, int64_t T, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Module handles.  Weights are handed over as HOST fp32 arrays under the reference's state-dict key names
+ * (key names are part of the contract); the library folds weight norm (weight_g / weight_v),
+ * re-tiles them for the MFMA kernels and uploads them.  *_finalize fails with DMEL_EMISSING when a required
+ * key was never set.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* WaveNet      replaces models/modules/wavenet.py:138-225 (forward :204-225, block :116-135) */
+typedef struct dmel_wavenet dmel_wavenet;
+int dmel_wavenet_create(dmel_wavenet** m, int input_channels /*0 = same as residual*/, int output_channels /*0 = none*/,
+                        int residual_channels, int residual_layers, int dilation_cycle, int condition_channels /*0 = none*/);
+void dmel_wavenet_destroy(dmel_wavenet* m);
+int dmel_wavenet_set_tensor(dmel_wavenet* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int dmel_wavenet_finalize(dmel_wavenet* m);
+size_t dmel_wavenet_workspace_bytes(const dmel_wavenet* m, int N, int64_t T);
+/* x (N, Cin, T), condition (N, Ccond, T) or NULL, y (N, Cout, T).
+ * in_lengths / out_lengths: NULL or N int64 frame counts; x is read as x * (t < in_lengths[n]) and y is
+ * written as y * (t < out_lengths[n])  (the mask multiplies of codec_lit_modules.py:471-477,505-506).
+ * group_repeat: lengths index = n / group_repeat (expand_mask, codec_lit_modules.py:156-157). */
+int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const float* condition, float* y, int N, int64_t T,
+                         const int64_t* in_lengths, const int64_t* out_lengths, int group_repeat,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* DownsampleFiniteScalarQuantize (is_dmel=True, n_codebooks=1)   replaces models/modules/dowmsample_fsq.py:124-147
+ * and vector_quantize_pytorch GroupedResidualFSQ.forward / get_output_from_indices. */
+typedef struct dmel_quantizer dmel_quantizer;
+int dmel_quantizer_create(dmel_quantizer** q, int input_dim /*= groups * dim_per_group*/, int n_groups,
+                          const int* levels, int n_levels, const int* downsample_factor, int n_factors,
+                          int fsq_prebound);
+void dmel_quantizer_destroy(dmel_quantizer* q);
+int dmel_quantizer_set_tensor(dmel_quantizer* q, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int dmel_quantizer_finalize(dmel_quantizer* q);
+size_t dmel_quantizer_workspace_bytes(const dmel_quantizer* q, int B, int64_t T);
+/* z (B*G, C, T) -> ids (B, G, T4) int32, T4 = T / prod(factors).  prequant (optional, may be NULL):
+ * (G, B, T4, n_levels) fp32, the bounded value that is rounded (for the near-tie analysis of the tests). */
+int dmel_quantizer_encode(const dmel_quantizer* q, const float* z, int32_t* ids, float* prequant, int B, int64_t T,
+                          void* workspace, size_t workspace_bytes, void* stream);
+/* ids (B, G, T4) -> z (B, G*C, T4*prod(factors)) */
+int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids, float* z, int B, int64_t T4,
+                          void* workspace, size_t workspace_bytes, void* stream);
+
+/* z[b,c,t] = z[b,c,t] * (t < lengths[b]) + (w[c] * value + bias[c])      codec_lit_modules.py:520-526
+ * (quality_projection = nn.Linear(1, C) applied to the constant 2.0).  w, bias: device (C). */
+int dmel_mask_add_quality_f32(float* z, const int64_t* lengths, const float* w, const float* bias, float value,
+                              int B, int C, int64_t T, void* stream);
+
+/* BigVGAN generator      replaces models/modules/bigvgan/bigvgan.py:367-393 (+ AMPBlock1 :132-141) */
+typedef struct dmel_bigvgan dmel_bigvgan;
+typedef struct dmel_bigvgan_config {
+  int num_mels;
+  int upsample_initial_channel;
+  int num_upsamples;
+  int upsample_rates[8];
+  int upsample_kernel_sizes[8];
+  int num_kernels;
+  int resblock_kernel_sizes[8];
+  int resblock_dilations[8][3];
+  int snake_logscale;      /* h.snake_logscale */
+  int activation_snake;    /* 1: "snake", 0: "snakebeta" */
+  int use_tanh_at_final;
+  int use_bias_at_final;
+} dmel_bigvgan_config;
+int dmel_bigvgan_create(dmel_bigvgan** m, const dmel_bigvgan_config* cfg);
+void dmel_bigvgan_destroy(dmel_bigvgan* m);
+int dmel_bigvgan_set_tensor(dmel_bigvgan* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int dmel_bigvgan_finalize(dmel_bigvgan* m);
+size_t dmel_bigvgan_workspace_bytes(const dmel_bigvgan* m, int B, int64_t T);
+/* mel (B, num_mels, T) -> audio (B, 1, T * prod(upsample_rates)) */
+int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, float* audio, int B, int64_t T,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-op entry point for the implicit-GEMM conv kernel (tests, module mirrors).
+ * y = conv1d(x, w, bias, dilation, padding = dilation*(k-1)/2)   w_host: (Cout, Cin, k) as nn.Conv1d stores it.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dmel_conv dmel_conv;
+int dmel_conv_create(dmel_conv** c, const float* w_host, const float* bias_host /*nullable*/, int Cout, int Cin, int k,
+                     int dilation);
+void dmel_conv_destroy(dmel_conv* c);
+int dmel_conv_forward(const dmel_conv* c, const float* x, float* y, int B, int64_t T, void* stream);
+
+/* Timing hook used by bench.py: when enabled, every launch of the named kernel family on `stream` is
+ * bracketed by hipEvents; dmel_prof_read returns the launch count and total milliseconds since the last reset
+ * (synchronises the events it reads).  family: "conv_igemm", "aa_snake", "stft_logmel", "small". */
+int dmel_prof_enable(int on);
+int dmel_prof_reset(void);
+int dmel_prof_read(const char* family, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMEL_HIP_H */

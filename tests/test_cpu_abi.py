@@ -1,0 +1,148 @@
+"""CPU-side checks of the boundary: the C-ABI library builds, loads without a GPU, exports every symbol
+include/dmel_hip.h declares, fails loudly (no fallback), and its host-side logic matches the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle import ref_cpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from dmel_codec_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        from dmel_codec_amd.build import build
+        build(verbose=False)
+    return _lib.lib()
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "dmel_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(dmel_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(L):
+    from dmel_codec_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(L, n), f"{n} declared in include/dmel_hip.h but not exported by libdmel_hip.so"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
+    assert L.dmel_abi_version() == 1
+
+
+def test_errors_are_loud_not_fallbacks(L):
+    from dmel_codec_amd import _lib
+    h = C.c_void_p()
+    rc = L.dmel_stft_plan_create(C.byref(h), 44100, 2048, 2048, 512, 128, 0.0, 0.0, None)
+    assert rc == -2 and b"n_fft" in L.dmel_last_error()
+    with pytest.raises(RuntimeError, match="n_fft"):
+        _lib.check(rc, "stft_plan_create")
+    lv = (C.c_int * 3)(7, 5, 5)
+    fs = (C.c_int * 2)(2, 3)
+    assert L.dmel_quantizer_create(C.byref(h), 700, 10, lv, 3, fs, 2, 1) == -2
+    assert L.dmel_quantizer_create(C.byref(h), 701, 10, lv, 3, fs, 2, 1) == -1
+    # CPU tensors are refused by the mirror modules (there is no CPU path)
+    from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
+    with pytest.raises(RuntimeError, match="GPU"):
+        LogMelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, n_mels=100)(torch.zeros(1, 4000))
+
+
+def test_missing_weights_are_reported(L):
+    h = C.c_void_p()
+    assert L.dmel_wavenet_create(C.byref(h), 10, 0, 70, 2, 4, 0) == 0
+    rc = L.dmel_wavenet_finalize(h)
+    assert rc == -3 and b"missing state-dict tensor 'input_projection.conv." in L.dmel_last_error()
+    w = torch.zeros(70, 11, 1)
+    shape = (C.c_int64 * 3)(70, 11, 1)
+    assert L.dmel_wavenet_set_tensor(h, b"input_projection.conv.weight", w.data_ptr(), shape, 3) == 0
+    bshape = (C.c_int64 * 1)(70)
+    assert L.dmel_wavenet_set_tensor(h, b"input_projection.conv.bias", w.data_ptr(), bshape, 1) == 0
+    assert L.dmel_wavenet_finalize(h) == -3 and b"shape" in L.dmel_last_error()
+    L.dmel_wavenet_destroy(h)
+
+
+def test_mel_basis_matches_oracle(L):
+    for sr, n_mels, fmax in ((24000, 100, 12000.0), (16000, 80, None), (24000, 80, None), (44100, 128, None)):
+        out = torch.empty(n_mels, 513)
+        assert L.dmel_mel_basis_host(sr, 1024, n_mels, 0.0, fmax or 0.0, out.data_ptr()) == 0
+        ref = ref_cpu.slaney_mel_basis(sr, 1024, n_mels, 0.0, fmax)
+        assert np.allclose(out.numpy(), ref, rtol=0, atol=1e-9)
+        assert np.array_equal(out.numpy() != 0, ref != 0)
+
+
+def test_mirror_state_dict_layout():
+    """Key names are part of the drop-in contract."""
+    from dmel_codec_amd.configs import build_codec
+    m = build_codec(n_mels=80, dmel_groups=8, encoder_layers=2, decoder_layers=2)
+    sd = m.state_dict()
+    for k, shape in {
+        "encoder.input_projection.conv.weight": (70, 10, 1),
+        "encoder.residual_layers.1.conv_layer.conv.weight": (140, 70, 3),
+        "encoder.residual_layers.0.output_projection.conv.bias": (140,),
+        "encoder.skip_projection.conv.weight": (70, 70, 1),
+        "quantizer.residual_fsq.rvqs.7.project_in.weight": (3, 70),
+        "quantizer.residual_fsq.rvqs.0.project_out.bias": (70,),
+        "quantizer.downsample.0.0.weight": (70, 70, 2),
+        "quantizer.downsample.1.1.dwconv.weight": (70, 1, 7),
+        "quantizer.downsample.0.1.pwconv1.weight": (280, 70),
+        "quantizer.upsample.1.0.weight": (70, 70, 2),
+        "quantizer.upsample.0.1.gamma": (70,),
+        "decoder.residual_layers.0.condition_projection.conv.weight": (1120, 560, 1),
+        "decoder.residual_layers.1.diffusion_projection.linear.weight": (560, 560),
+        "decoder.output_projection.conv.weight": (80, 560, 1),
+        "quality_projection.weight": (560, 1),
+        "vocoder.conv_pre.weight_g": (512, 1, 1),
+        "vocoder.conv_pre.weight_v": (512, 80, 7),
+        "vocoder.ups.0.0.weight_v": (512, 256, 16),
+        "vocoder.resblocks.0.convs1.2.weight_v": (256, 256, 3),
+        "vocoder.resblocks.11.activations.5.act.beta": (32,),
+        "vocoder.resblocks.3.activations.0.upsample.filter": (1, 1, 12),
+        "vocoder.resblocks.3.activations.0.downsample.lowpass.filter": (1, 1, 12),
+        "vocoder.activation_post.act.alpha": (32,),
+        "vocoder.conv_post.weight_v": (1, 32, 7),
+    }.items():
+        assert k in sd, k
+        assert tuple(sd[k].shape) == shape, (k, tuple(sd[k].shape))
+    assert "decoder.input_projection.conv.weight" not in sd      # 560 == 560: wavenet.py:152-156
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/dmel_codec"), reason="reference only exists in the build container")
+def test_mirror_state_dicts_equal_reference_modules():
+    import subprocess
+    import sys
+    code = r"""
+import sys, warnings
+warnings.filterwarnings('ignore')
+sys.path.insert(0, '/root/reference'); sys.path.insert(0, %r)
+sys.dont_write_bytecode = True
+from dmel_codec.models.modules.wavenet import WaveNet as RW
+from dmel_codec.models.modules.bigvgan.bigvgan import BigVGAN as RB
+from dmel_codec.models.modules.bigvgan.env import AttrDict as RA
+from dmel_codec.models.modules.firefly import ConvNeXtBlock as RC
+from dmel_codec_amd.models.modules.wavenet import WaveNet
+from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+from dmel_codec_amd.models.modules.firefly import ConvNeXtBlock
+from dmel_codec_amd.configs import bigvgan_h, BIGVGAN
+def same(a, b):
+    sa = {k: tuple(v.shape) for k, v in a.state_dict().items()}
+    sb = {k: tuple(v.shape) for k, v in b.state_dict().items()}
+    assert sa == sb, (set(sa) ^ set(sb))
+same(RW(10, None, 70, 20, 4), WaveNet(10, None, 70, 20, 4))
+same(RW(64, 20, 64, 3, 4, False, 64), WaveNet(64, 20, 64, 3, 4, False, 64))
+same(RC(70), ConvNeXtBlock(70))
+for name in ('base_24k_100band',):
+    r, m = RB(RA(dict(BIGVGAN[name]))), BigVGAN(bigvgan_h(name))
+    same(r, m)
+    r.remove_weight_norm(); m.remove_weight_norm()
+    same(r, m)
+print('ok')
+""" % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]

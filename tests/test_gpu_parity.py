@@ -1,0 +1,346 @@
+"""GPU parity tests: the HIP path (through the C ABI of libdmel_hip.so) against the CPU oracle
+(oracle/ref_cpu.py) on the same seeded inputs and against the golden fixtures generated from the reference.
+
+Bars (BASELINE.json north_star): integer outputs (token ids) bit-exact; fp32 tensors within 1e-4 relative,
+where relative = max|a-b| / max|b| (conftest.rel_err)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from oracle import ref_cpu
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def cpu_sd(module):
+    return {k: v.detach().cpu().float() for k, v in module.state_dict().items()}
+
+
+def randomise(module, seed, scale=1.0):
+    """O(1) weights so every term of the arithmetic matters (default inits are ~0.02 / 1e-6)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in module.named_parameters():
+            leaf = name.split(".")[-1]
+            if leaf in ("alpha", "beta"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+            elif leaf == "gamma":
+                p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+            elif leaf == "weight_g":
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            elif p.ndim >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * (scale / p[0].numel() ** 0.5))
+            elif leaf == "weight":
+                p.copy_(1.0 + torch.randn(p.shape, generator=g) * 0.2)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.1)
+
+
+# ------------------------------------------------------------------------------------ STFT / log-mel
+def test_stft_logmel_golden(dev, golden):
+    from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
+    g = golden("stft_logmel")
+    for tag, (sr, n_mels, fmax) in g.meta["cases"].items():
+        m = LogMelSpectrogram(sample_rate=sr, n_fft=1024, win_length=1024, hop_length=256, n_mels=n_mels, f_min=0, f_max=fmax)
+        y = m(g.ins[tag].to(dev))
+        assert y.shape == g.outs[tag].shape
+        assert rel_err(y, g.outs[tag]) < TOL, tag
+        # the library's mel basis against the oracle's restatement
+        assert torch.allclose(m.spectrogram.mel_basis(), torch.from_numpy(ref_cpu.slaney_mel_basis(sr, 1024, n_mels, 0.0, fmax)),
+                              atol=1e-9)
+
+
+@pytest.mark.parametrize("L,hop,B", [(385 + 640, 256, 1), (24000, 256, 3), (16000, 256, 2), (7777, 128, 2), (24000 * 10, 256, 2),
+                                      (5000, 320, 1)])
+def test_stft_logmel_random(dev, L, hop, B):
+    from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
+    torch.manual_seed(L)
+    x = torch.randn(B, 1, L) * 0.3
+    m = LogMelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=hop, n_mels=100, f_min=0, f_max=12000)
+    y = m(x.to(dev))
+    ref = ref_cpu.stft_logmel(x, 24000, 1024, 1024, hop, 100, 0.0, 12000.0)
+    assert y.shape == ref.shape == (B, 100, 1 + (L + 2 * ((1024 - hop) // 2) - 1024) // hop)
+    assert rel_err(y, ref) < TOL
+    # (B, L) input and the fused length mask
+    lens = torch.tensor([L - 300 * i for i in range(B)])
+    y2 = m(x[:, 0].to(dev), lengths=lens.to(dev))
+    mask = ref_cpu.sequence_mask(lens // hop, ref.shape[2])[:, None, :].float()
+    assert rel_err(y2, ref * mask) < TOL
+    assert torch.equal(y2.cpu() == 0, (ref * mask) == 0)
+
+
+def test_stft_rejects_unsupported(dev):
+    from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
+    with pytest.raises(RuntimeError, match="n_fft"):
+        LogMelSpectrogram(sample_rate=44100, n_fft=2048, win_length=2048, hop_length=512, n_mels=128)(torch.zeros(1, 9000, device=dev))
+    with pytest.raises(RuntimeError, match="GPU"):
+        LogMelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, n_mels=80)(torch.zeros(1, 9000))
+    with pytest.raises(RuntimeError, match="reflect pad"):
+        LogMelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, n_mels=80)(torch.zeros(1, 300, device=dev))
+
+
+# ------------------------------------------------------------------------------------ implicit-GEMM conv
+@pytest.mark.parametrize("Cout,Cin,k,dil,T,B", [
+    (32, 32, 3, 1, 100, 2), (32, 32, 11, 5, 300, 2), (64, 64, 7, 3, 257, 1), (128, 128, 3, 5, 130, 2),
+    (256, 256, 11, 1, 96, 1), (140, 70, 3, 8, 93, 3), (1, 32, 7, 1, 500, 2), (512, 100, 7, 1, 92, 2),
+    (70, 280, 1, 1, 23, 5), (100, 700, 1, 1, 92, 1), (33, 17, 5, 2, 65, 1),
+])
+def test_conv_igemm(dev, Cout, Cin, k, dil, T, B):
+    from dmel_codec_amd import _lib
+    torch.manual_seed(Cout * 1000 + Cin + k)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    b = torch.randn(Cout) * 0.1
+    x = torch.randn(B, Cin, T)
+    ref = F.conv1d(x, w, b, dilation=dil, padding=dil * (k - 1) // 2)
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), b.data_ptr(), Cout, Cin, k, dil))
+    xd = x.to(dev)
+    y = torch.empty(B, Cout, T, device=dev)
+    _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    L.dmel_conv_destroy(h)
+    assert rel_err(y, ref) < 2e-5
+
+
+# ------------------------------------------------------------------------------------ anti-aliased snake
+def test_activation1d_golden(dev, golden):
+    from dmel_codec_amd.models.modules.bigvgan.alias_free_activation.act import Activation1d
+    from dmel_codec_amd.models.modules.bigvgan import activations
+    for kind in ("snakebeta", "snake"):
+        g = golden("activation1d_" + kind)
+        act = (activations.SnakeBeta if kind == "snakebeta" else activations.Snake)(6, alpha_logscale=True)
+        m = Activation1d(activation=act)
+        m.load_state_dict(g.sd)
+        m = m.to(dev)
+        for t in g.meta["lengths"]:
+            y = m(g.ins[f"x{t}"].to(dev))
+            assert rel_err(y, g.outs[f"y{t}"]) < 1e-5, (kind, t)
+
+
+@pytest.mark.parametrize("B,Cc,T", [(2, 5, 1023), (1, 3, 1024), (2, 2, 1025), (1, 4, 5000), (3, 32, 333)])
+def test_activation1d_tiles(dev, B, Cc, T):
+    from dmel_codec_amd import _lib
+    torch.manual_seed(T)
+    x = torch.randn(B, Cc, T) * 2
+    alpha, beta = torch.randn(Cc) * 0.5, torch.randn(Cc) * 0.5
+    for logscale in (True, False):
+        a = alpha if logscale else alpha.abs() + 0.5
+        bt = beta if logscale else beta.abs() + 0.5
+        ref = ref_cpu.activation1d(x, a, bt, logscale=logscale)
+        y = torch.empty(B, Cc, T, device=dev)
+        taps = ref_cpu.aa_filter12().view(-1).contiguous()
+        _lib.check(_lib.lib().dmel_aa_snake_f32(x.to(dev).data_ptr(), y.data_ptr(), a.to(dev).data_ptr(), bt.to(dev).data_ptr(),
+                                                taps.data_ptr(), int(logscale), B, Cc, T, _lib.stream_ptr()))
+        assert rel_err(y, ref) < 1e-5
+
+
+# ------------------------------------------------------------------------------------ WaveNet
+def test_wavenet_golden(dev, golden):
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    g = golden("wavenet_enc")
+    m = WaveNet(input_channels=10, residual_channels=70, residual_layers=g.meta["n_layers"], dilation_cycle=4)
+    m.load_state_dict(g.sd)
+    y = m.to(dev)(g.ins["x"].to(dev))
+    assert rel_err(y, g.outs["y"]) < TOL
+    g = golden("wavenet_dec")
+    m = WaveNet(input_channels=48, output_channels=20, residual_channels=48, residual_layers=g.meta["n_layers"],
+                dilation_cycle=4, condition_channels=48)
+    m.load_state_dict(g.sd)
+    y = m.to(dev)(g.ins["x"].to(dev), condition=g.ins["cond"].to(dev))
+    assert rel_err(y, g.outs["y"]) < TOL
+
+
+def test_wavenet_real_widths_and_masks(dev):
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    # encoder shape of the reference configs (10 -> 70, 20 layers), ragged lengths, group repeat
+    m = WaveNet(input_channels=10, residual_channels=70, residual_layers=20, dilation_cycle=4)
+    randomise(m, 1)
+    torch.manual_seed(2)
+    G, B, T = 4, 3, 93
+    x = torch.randn(B * G, 10, T)
+    lens = torch.tensor([93, 40, 77])
+    mask = ref_cpu.sequence_mask(lens, T)[:, None, :].float().repeat_interleave(G, dim=0)
+    ref = ref_cpu.wavenet_forward(cpu_sd(m), "", x, 20) * mask
+    y = m.to(dev)(x.to(dev), out_lengths=lens.to(dev), group_repeat=G)
+    assert rel_err(y, ref) < TOL
+    # decoder shape (700 wide, conditioned, 100 out), 3 layers to keep the oracle quick
+    m = WaveNet(input_channels=700, output_channels=100, residual_channels=700, residual_layers=3, dilation_cycle=4,
+                condition_channels=700)
+    randomise(m, 3)
+    x, c = torch.randn(2, 700, 92), torch.randn(2, 700, 92)
+    lens = torch.tensor([92, 60])
+    mask = ref_cpu.sequence_mask(lens, 92)[:, None, :].float()
+    ref = ref_cpu.wavenet_forward(cpu_sd(m), "", x * mask, 3, condition=c) * mask
+    y = m.to(dev)(x.to(dev), condition=c.to(dev), in_lengths=lens.to(dev), out_lengths=lens.to(dev))
+    assert rel_err(y, ref) < TOL
+
+
+# ------------------------------------------------------------------------------------ quantiser
+def near_tie_report(ids_gpu, ids_ref, pre_ref, eps=2e-4):
+    """ids must match wherever the oracle's pre-round value is farther than eps from a rounding boundary
+    (x.5); at a near-tie either neighbour is accepted.  pre_ref: (G, B, L, D); ids: (B, G, L)."""
+    frac = (pre_ref - torch.floor(pre_ref) - 0.5).abs().amin(dim=-1)        # (G, B, L)
+    tie = (frac < eps).permute(1, 0, 2)
+    diff = ids_gpu.cpu() != ids_ref
+    return int(diff.sum()), int((diff & ~tie).sum()), int(tie.sum())
+
+
+@pytest.mark.parametrize("levels,prebound", [([7, 5, 5], True), ([7, 5, 5], False), ([8, 6], True)])
+def test_quantizer_encode_decode(dev, levels, prebound):
+    from dmel_codec_amd.models.modules.dowmsample_fsq import DownsampleFiniteScalarQuantize
+    G, Cg, B, T = 10, 70, 3, 93
+    q = DownsampleFiniteScalarQuantize(input_dim=G * Cg, n_codebooks=1, n_groups=G, levels=levels, downsample_factor=(2, 2),
+                                       is_dmel=True, fsq_prebound=prebound)
+    randomise(q, 5, scale=1.5)
+    torch.manual_seed(6)
+    z = torch.randn(B * G, Cg, T)
+    sd = cpu_sd(q)
+    ids_ref, pre_ref = ref_cpu.quantizer_encode(sd, "", z, G, levels, (2, 2), prebound, return_prequant=True)
+    ids, pre = q.to(dev).encode(z.to(dev), return_prequant=True)
+    assert ids.dtype == torch.int32 and ids.shape == ids_ref.shape == (B, G, T // 4)
+    assert (pre.cpu() - pre_ref).abs().max() < 5e-5
+    n_diff, n_bad, n_tie = near_tie_report(ids, ids_ref, pre_ref)
+    assert n_bad == 0, f"{n_bad} id mismatches away from rounding boundaries ({n_diff} total, {n_tie} near-ties)"
+    assert len(torch.unique(ids_ref)) > 20          # the test exercises many codes
+    # decode: table lookup + Linear + upsampling, compared on the ORACLE's ids
+    zq_ref = ref_cpu.quantizer_decode(sd, "", ids_ref, G, levels, (2, 2))
+    zq = q.decode(ids_ref.to(dev))
+    assert zq.shape == zq_ref.shape == (B, G * Cg, (T // 4) * 4)
+    assert rel_err(zq, zq_ref) < TOL
+
+
+# ------------------------------------------------------------------------------------ BigVGAN
+def test_bigvgan_golden(dev, golden):
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    from dmel_codec_amd.models.modules.bigvgan.env import AttrDict
+    g = golden("bigvgan_tiny")
+    m = BigVGAN(AttrDict(dict(g.meta["h"])))
+    m.load_state_dict(g.sd)
+    y = m.to(dev)(g.ins["mel"].to(dev))
+    assert y.shape == g.outs["audio"].shape
+    assert rel_err(y, g.outs["audio"]) < TOL
+    g = golden("bigvgan_tiny_snake_nowm")
+    m = BigVGAN(AttrDict(dict(g.meta["h"])))
+    m.remove_weight_norm()
+    m.load_state_dict(g.sd)
+    y = m.to(dev)(g.ins["mel"].to(dev))
+    assert rel_err(y, g.outs["audio"]) < TOL
+
+
+def test_bigvgan_base_config(dev):
+    """BigVGAN-base (BASELINE config 2 vocoder, 14 M parameters) on a short mel against the oracle."""
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    from dmel_codec_amd.configs import bigvgan_h
+    h = bigvgan_h("base_24k_100band", num_mels=80)
+    torch.manual_seed(11)
+    m = BigVGAN(h)
+    randomise(m, 12, scale=0.7)
+    mel = torch.randn(2, 80, 12)
+    ref = ref_cpu.bigvgan_forward(cpu_sd(m), dict(h), mel)
+    y = m.to(dev)(mel.to(dev))
+    assert y.shape == ref.shape == (2, 1, 12 * 256)
+    assert rel_err(y, ref) < TOL
+
+
+# ------------------------------------------------------------------------------------ whole codec
+def make_codec(seed, **kw):
+    from dmel_codec_amd.configs import build_codec
+    torch.manual_seed(seed)
+    codec = build_codec(**kw)
+    randomise(codec.encoder, seed + 1)
+    randomise(codec.quantizer, seed + 2, scale=1.5)
+    randomise(codec.decoder, seed + 3)
+    if codec.vocoder is not None:
+        randomise(codec.vocoder, seed + 4, scale=0.7)
+    with torch.no_grad():
+        codec.quality_projection.weight.normal_(0, 0.3)
+        codec.quality_projection.bias.normal_(0, 0.1)
+    return codec
+
+
+def split_sd(codec):
+    sd = cpu_sd(codec)
+    voc = {k[len("vocoder."):]: v for k, v in sd.items() if k.startswith("vocoder.")}
+    return {k: v for k, v in sd.items() if not k.startswith("vocoder.")}, voc
+
+
+@pytest.mark.parametrize("n_mels,G,sr,L", [(80, 8, 16000, 16000), (100, 10, 24000, 24000)])
+def test_codec_encode_ids_bit_exact(dev, n_mels, G, sr, L):
+    """BASELINE config 1 (1 s, 16 kHz, 80 mel, 8 groups) and the reference default (24 kHz, 100 mel, 10 groups):
+    encode() token ids against the oracle, ragged batch."""
+    from dmel_codec_amd.configs import oracle_cfg
+    codec = make_codec(100 + G, sample_rate=sr, n_mels=n_mels, dmel_groups=G, vocoder=None,
+                       f_max=None if sr == 16000 else 12000.0)
+    cfg = oracle_cfg(codec)
+    sd, _ = split_sd(codec)
+    gen = torch.Generator().manual_seed(1234)
+    audio = torch.randn(3, 1, L, generator=gen)
+    audio = 0.95 * audio / audio.abs().amax(dim=-1, keepdim=True)
+    lens = torch.tensor([[L, L - 5000, L // 2]])            # (1, B) as the reference's collate emits
+    ids_ref, lens_ref, pre_ref = ref_cpu.vqgan_encode(sd, cfg, audio, lens, return_prequant=True)
+    codec = codec.to(dev)
+    ids, ilens = codec.encode(audio.to(dev), lens.to(dev))
+    assert ids.dtype == torch.int32 and ids.shape == ids_ref.shape == (3, G, (L // 256) // 4)
+    assert torch.equal(ilens.cpu(), lens_ref)
+    n_diff, n_bad, n_tie = near_tie_report(ids, ids_ref, pre_ref)
+    assert n_bad == 0, f"{n_bad} id mismatches away from rounding boundaries ({n_diff} total, {n_tie} near-ties)"
+    assert n_diff <= n_tie
+    assert int(ids.max()) < math.prod(cfg["levels"]) and int(ids.min()) >= 0
+
+
+def test_codec_decode_waveform(dev):
+    """decode(): ids -> quantised latent -> conditional WaveNet (noise injected) -> BigVGAN, against the oracle."""
+    from dmel_codec_amd.configs import oracle_cfg
+    codec = make_codec(300, n_mels=80, dmel_groups=8, decoder_layers=4, encoder_layers=2)
+    cfg = oracle_cfg(codec)
+    sd, voc_sd = split_sd(codec)
+    B, T4 = 2, 6
+    gen = torch.Generator().manual_seed(4321)
+    ids = torch.randint(0, 175, (B, 8, T4), generator=gen, dtype=torch.int32)
+    flen = torch.tensor([T4, 4])
+    noise = torch.randn(B, 560, T4 * 4, generator=gen)
+    audio_ref, mel_ref = ref_cpu.vqgan_decode(sd, cfg, ids, flen, noise, voc_sd, dict(codec.vocoder.h))
+    codec = codec.to(dev)
+    audio, mel = codec.decode(ids.to(dev), flen.to(dev), return_audios=True, noise=noise.to(dev))
+    assert mel.shape == mel_ref.shape and audio.shape == audio_ref.shape == (B, 1, T4 * 4 * 256)
+    assert rel_err(mel, mel_ref) < TOL
+    assert rel_err(audio, audio_ref) < TOL
+    z_ref, _ = ref_cpu.vqgan_quantized_features(sd, cfg, ids, flen)
+    z, _ = codec.get_quantized_features_from_indices(ids.to(dev), flen.to(dev))
+    assert rel_err(z, z_ref) < TOL
+
+
+def test_codec_round_trip_properties(dev):
+    """Size-independent properties at a larger size than the oracle is asked to check: determinism, batch
+    independence (an item's ids do not depend on its neighbours) and mask behaviour."""
+    codec = make_codec(500, n_mels=80, dmel_groups=8, vocoder=None).to(dev)
+    gen = torch.Generator().manual_seed(7)
+    B, L = 8, 24000 * 2
+    audio = (torch.randn(B, 1, L, generator=gen) * 0.2).to(dev)
+    lens = torch.full((B,), L, device=dev)
+    ids1, l1 = codec.encode(audio, lens)
+    ids2, _ = codec.encode(audio, lens)
+    assert torch.equal(ids1, ids2)
+    ids_sub, _ = codec.encode(audio[2:5], lens[2:5])
+    assert torch.equal(ids_sub, ids1[2:5])
+    assert int(l1[0]) == (L // 256) // 4
+    noise = torch.randn(B, 560, ids1.shape[2] * 4, generator=gen).to(dev)
+    mel = codec.decode(ids1, l1, noise=noise)
+    short = l1.clone()
+    short[0] = 5
+    mel2 = codec.decode(ids1, short, noise=noise)
+    assert torch.all(mel2[0, :, 20:] == 0) and torch.equal(mel2[1:], mel[1:])
