@@ -43,11 +43,12 @@ class VQGAN(nn.Module):
             vocoder.load_state_dict(torch.load(vocoder.ckpt_path, map_location="cpu")["generator"], strict=True)
             keep = True
         else:
-            keep = vocoder is not None and not load_vocoder_ckpt
+            keep = not load_vocoder_ckpt
         if keep:
-            self.vocoder = vocoder.eval()
-            for p in self.vocoder.parameters():
-                p.requires_grad = False
+            self.vocoder = vocoder.eval() if vocoder is not None else None
+            if self.vocoder is not None:
+                for p in self.vocoder.parameters():
+                    p.requires_grad = False
             self.decoder, self.discriminator = decoder, discriminator
         else:
             self.vocoder, self.decoder, self.discriminator = None, None, None

@@ -50,6 +50,36 @@ def randomise(module, seed, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ STFT / log-mel
+def assert_logmel_close(y, ref, what=""):
+    """fp32 parity bar for log-mel: 1e-4 relative on the mel energies, with an absolute floor of 1e-6 of full
+    scale (-120 dB).  Below that floor a tonal input's bins hold nothing but the fp32 rounding noise of the FFT
+    itself (windowing alone injects ~6e-8 relative per sample), which differs between ANY two FFT implementations
+    and which the log then magnifies; the oracle's torch.stft is no closer to an fp64 DFT there than the kernel is
+    (test_stft_noise_floor_vs_fp64)."""
+    a, b = torch.exp(y.detach().double().cpu()), torch.exp(ref.double())
+    tol = 1e-4 * b + 1e-6 * b.max()
+    bad = (a - b).abs() > tol
+    assert not bad.any(), f"{what}: {int(bad.sum())} mel values differ, worst {float(((a - b).abs() / tol).max()):.2f}x tolerance"
+
+
+def test_stft_noise_floor_vs_fp64(dev, golden):
+    """The sweep fixture has ~160 dB of dynamic range per frame; check the kernel against an fp64 DFT and show it
+    is as close to the truth as the fp32 oracle is."""
+    from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
+    g = golden("stft_logmel")
+    x = g.ins["24k100"][:1]
+    m = LogMelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, n_mels=100, f_min=0, f_max=12000)
+    y = torch.exp(m(x.to(dev)).double().cpu())
+    xp = F.pad(x.double().unsqueeze(1), (384, 384), mode="reflect")[0, 0]
+    frames = xp.unfold(0, 1024, 256) * torch.hann_window(1024, dtype=torch.float64)
+    mag = torch.sqrt(torch.fft.rfft(frames, dim=-1).abs() ** 2 + 1e-9).T
+    truth = torch.clamp(torch.from_numpy(ref_cpu.slaney_mel_basis(24000, 1024, 100, 0.0, 12000.0)).double() @ mag, min=1e-5)
+    oracle = torch.exp(g.outs["24k100"][0].double())
+    err_gpu = ((y[0] - truth).abs() / truth).max()
+    err_oracle = ((oracle - truth).abs() / truth).max()
+    assert err_gpu < max(2.0 * err_oracle, 1e-5), (float(err_gpu), float(err_oracle))
+
+
 def test_stft_logmel_golden(dev, golden):
     from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
     g = golden("stft_logmel")
@@ -57,7 +87,8 @@ def test_stft_logmel_golden(dev, golden):
         m = LogMelSpectrogram(sample_rate=sr, n_fft=1024, win_length=1024, hop_length=256, n_mels=n_mels, f_min=0, f_max=fmax)
         y = m(g.ins[tag].to(dev))
         assert y.shape == g.outs[tag].shape
-        assert rel_err(y, g.outs[tag]) < TOL, tag
+        assert_logmel_close(y, g.outs[tag], tag)
+        assert rel_err(y[1], g.outs[tag][1]) < TOL, tag       # the broadband (noise) clip: plain log-domain bar
         # the library's mel basis against the oracle's restatement
         assert torch.allclose(m.spectrogram.mel_basis(), torch.from_numpy(ref_cpu.slaney_mel_basis(sr, 1024, n_mels, 0.0, fmax)),
                               atol=1e-9)
@@ -74,6 +105,7 @@ def test_stft_logmel_random(dev, L, hop, B):
     ref = ref_cpu.stft_logmel(x, 24000, 1024, 1024, hop, 100, 0.0, 12000.0)
     assert y.shape == ref.shape == (B, 100, 1 + (L + 2 * ((1024 - hop) // 2) - 1024) // hop)
     assert rel_err(y, ref) < TOL
+    assert_logmel_close(y, ref)
     # (B, L) input and the fused length mask
     lens = torch.tensor([L - 300 * i for i in range(B)])
     y2 = m(x[:, 0].to(dev), lengths=lens.to(dev))
@@ -143,7 +175,8 @@ def test_activation1d_tiles(dev, B, Cc, T):
         ref = ref_cpu.activation1d(x, a, bt, logscale=logscale)
         y = torch.empty(B, Cc, T, device=dev)
         taps = ref_cpu.aa_filter12().view(-1).contiguous()
-        _lib.check(_lib.lib().dmel_aa_snake_f32(x.to(dev).data_ptr(), y.data_ptr(), a.to(dev).data_ptr(), bt.to(dev).data_ptr(),
+        xd, ad, bd = x.to(dev), a.to(dev), bt.to(dev)      # keep the device buffers alive across the launch
+        _lib.check(_lib.lib().dmel_aa_snake_f32(xd.data_ptr(), y.data_ptr(), ad.data_ptr(), bd.data_ptr(),
                                                 taps.data_ptr(), int(logscale), B, Cc, T, _lib.stream_ptr()))
         assert rel_err(y, ref) < 1e-5
 
