@@ -1,0 +1,205 @@
+"""Headline benchmark: audio-seconds per wall-second of the encode()+decode() round trip (1/RTF).
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1]): full codec inference at 24 kHz, 80 mel bins, 8 FSQ groups, BigVGAN-base
+vocoder, batch 32 of 1 s clips per GPU, fp32.  A "step" is one encode() + decode(return_audios=True) over one
+batch already resident in HBM; weights are seeded random (the reference ships none), audio is synthetic.
+One process per GPU; utterances shard across ranks with no data-path collective (weak scaling).  Rank 0 prints
+ONE JSON line with the whole-job rate, the roofline of the dominant kernel (the fp32-MFMA implicit-GEMM conv,
+timed live with hipEvents on the launch stream) and, at N=1, the CPU baseline (the oracle restatement made of
+the ATen-CPU calls the reference itself makes) timed on the host cores in the same run.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+WORKLOADS = {
+    # BASELINE.json configs[1]
+    "cfg2": dict(sample_rate=24000, n_mels=80, dmel_groups=8, levels=(7, 5, 5), vocoder="base_24k_100band", f_max=None),
+    # the reference's own default shapes (config/codec/dMel_example.yaml + stage/pretrain.yaml): 100 mel, 10 groups
+    "cfg2r": dict(sample_rate=24000, n_mels=100, dmel_groups=10, levels=(7, 5, 5), vocoder="base_24k_100band", f_max=12000.0),
+}
+
+
+def synth_audio(batch: int, samples: int, seed: int) -> torch.Tensor:
+    """Seeded N(0,1), low-passed, peak-normalised x0.95 (mirrors dataset/lhotse_tts_dataset.py:29-32)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(batch, 1, samples, generator=g)
+    k = torch.hann_window(9, periodic=False)
+    x = torch.nn.functional.conv1d(x, (k / k.sum()).view(1, 1, -1), padding=4)
+    return 0.95 * x / x.abs().amax(dim=-1, keepdim=True)
+
+
+def build(workload: str, seed: int = 114514):
+    from dmel_codec_amd.configs import build_codec
+    torch.manual_seed(seed)      # seed of config/codec/dMel_example.yaml:2
+    codec = build_codec(**WORKLOADS[workload])
+    # BigVGAN's default init (weights ~ N(0, 0.01)) drives a random network's output to ~0; give the vocoder unit-gain
+    # weights so the timed data path carries realistic magnitudes (timing does not depend on values, sin/tanh ranges do)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, p in codec.vocoder.named_parameters():
+            if name.endswith("weight_v"):
+                p.copy_(torch.randn(p.shape, generator=g) / p[0].numel() ** 0.5)
+            elif name.endswith("weight_g"):
+                p.fill_(1.0)
+    return codec.eval()
+
+
+def cpu_baseline(codec, workload: str, seconds_per_clip: float, budget_s: float):
+    """Time the oracle (CPU restatement, kind 'port') on a bounded sample of the same workload."""
+    from dmel_codec_amd.configs import oracle_cfg
+    from oracle import ref_cpu
+    cfg = oracle_cfg(codec)
+    sd = {k: v.detach().cpu().float() for k, v in codec.state_dict().items()}
+    voc = {k[len("vocoder."):]: v for k, v in sd.items() if k.startswith("vocoder.")}
+    sd = {k: v for k, v in sd.items() if not k.startswith("vocoder.")}
+    h = dict(codec.vocoder.h)
+    n_lat = codec.decoder.input_channels
+    n = 2
+    L = int(cfg["sample_rate"] * seconds_per_clip)
+    audio = synth_audio(n, L, 99)
+    lens = torch.full((n,), L)
+    cores = torch.get_num_threads()
+
+    def one():
+        with torch.no_grad():
+            ids, il = ref_cpu.vqgan_encode(sd, cfg, audio, lens)
+            noise = torch.randn(n, n_lat, ids.shape[2] * 4)
+            a, _ = ref_cpu.vqgan_decode(sd, cfg, ids, il, noise, voc, h)
+        return a
+
+    one()                                    # warm-up (thread pools, oneDNN primitives)
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 20:
+            break
+    return {"value": round(n * seconds_per_clip * reps / el, 3), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "sample": f"{reps} x (encode+decode of {n} x {seconds_per_clip:g} s clips) through oracle/ref_cpu.py "
+                      f"(torch.stft / F.conv1d / F.conv_transpose1d on {cores} threads), {el:.1f} s of CPU work"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU per step")
+    ap.add_argument("--seconds", type=float, default=1.0, help="clip length")
+    ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch (python -m torch.distributed.run "
+                             f"--nproc-per-node {args.gpus} bench.py ...)")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group("nccl", device_id=dev)    # RCCL
+        dist = dist_mod
+
+    from dmel_codec_amd import _lib
+    codec = build(args.workload).to(dev)
+    sr = WORKLOADS[args.workload]["sample_rate"]
+    L = int(sr * args.seconds)
+    audio = synth_audio(args.batch, L, 1234 + rank).to(dev)      # every rank its own utterances
+    lens = torch.full((args.batch,), L, device=dev, dtype=torch.int64)
+
+    def step():
+        ids, il = codec.encode(audio, lens)
+        wav, _ = codec.decode(ids, il, return_audios=True)       # draws its Gaussian noise like the reference (:473)
+        return ids, wav
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    _lib.prof_reset()
+    _lib.prof_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ids, wav = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    _lib.prof_enable(False)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(wav).all() and wav.shape == (args.batch, 1, (L // 256 // 4) * 4 * 256)
+
+    conv = _lib.prof_read("conv_igemm")
+    snake = _lib.prof_read("aa_snake")
+    stft = _lib.prof_read("stft_logmel")
+    small = _lib.prof_read("small")
+    _lib.prof_reset()
+
+    if rank == 0:
+        audio_s = world * args.batch * args.seconds * args.steps
+        ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
+        out = {
+            "metric": "audio-sec/sec (encode+decode RTF) @24 kHz batch 32",
+            "value": round(audio_s / elapsed, 2),
+            "unit": "audio-sec/sec",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: encode+decode, {sr} Hz, {WORKLOADS[args.workload]['n_mels']} mel, "
+                                   f"{WORKLOADS[args.workload]['dmel_groups']} FSQ groups {list(WORKLOADS[args.workload]['levels'])}, "
+                                   f"WaveNet 20+20 layers, BigVGAN-base, batch {args.batch} x {args.seconds:g} s per GPU",
+                       "parallelism": f"{world} x independent utterance shards, no collective"},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
+                         "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": conv["launches"] // max(1, args.steps),
+                         "avg_launch_us": round(1e3 * conv["ms"] / max(1, conv["launches"]), 2),
+                         "gflop_per_step": round(conv["flops"] / args.steps / 1e9, 1)},
+            "kernel_ms_per_step": {"conv_igemm": round(conv["ms"] / args.steps, 3), "aa_snake": round(snake["ms"] / args.steps, 3),
+                                   "stft_logmel": round(stft["ms"] / args.steps, 4), "small": round(small["ms"] / args.steps, 3)},
+            "aa_snake_hbm": {"achieved_GBs": round(snake["bytes"] / (snake["ms"] * 1e-3) / 1e9, 1) if snake["ms"] > 0 else 0.0,
+                             "peak_GBs": PEAK_HBM_GBS},
+        }
+        if world == 1 and args.cpu_budget > 0:
+            out["cpu_baseline"] = cpu_baseline(codec.cpu(), args.workload, args.seconds, args.cpu_budget)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
