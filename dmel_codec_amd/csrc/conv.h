@@ -69,12 +69,13 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream);
 
 // ---- host packing (template, header-only) ---------------------------------------------------
 inline int choose_bm(int M) {
-  int best = 128, best_pad = (int)align_up(M, 128);
-  for (int bm : {64, 32}) {
-    int p = (int)align_up(M, bm);
-    if (p < best_pad) { best = bm; best_pad = p; }
+  // Largest tile whose zero-row padding stays under ~12 %: big tiles reuse each staged x row across more
+  // output rows; a few dead rows are far cheaper than 32-row tiles on a 1000-row GEMM.
+  for (int bm : {128, 64}) {
+    const int p = (int)align_up(M, bm);
+    if ((p - M) * 8 <= M) return bm;
   }
-  return best;
+  return 32;
 }
 
 template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, FW get_w, FB get_b) {

@@ -56,11 +56,12 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArgs a) {
-  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NTHR = 64 * WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
   constexpr int XS = BN + 64;                      // staged x row: BN columns + up to 64 halo
-  constexpr int XL = (kCK * XS + NTHR - 1) / NTHR; // x elements per thread per chunk
+  constexpr int RW = (kCK + NW - 1) / NW;          // x rows staged per wave
+  constexpr int XC = (XS + 63) / 64;               // 64-column groups per x row
   constexpr int WL = (kCK * BM / 4 + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                  // [2][kCK][XS]
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
   const int h = lane >> 5, l31 = lane & 31;
-  const int64_t q0 = (int64_t)blockIdx.x * BN;
+  const int q0 = blockIdx.x * BN;
   const int mblk = blockIdx.y, b = blockIdx.z;
   const int lb = b / a.len_div;
 
@@ -82,53 +83,66 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
   const float* wbase = a.w + (size_t)mblk * a.steps * (kCK * BM);
-  float xr[XL];
-  float4 wr[WL];
+  float xr[RW][XC];
+  static_assert(WL <= 2, "weight staging assumes at most two float4 per thread");
+  float4 wr0 = make_float4(0.f, 0.f, 0.f, 0.f), wr1 = wr0;  // named scalars: an indexed float4 array lands in scratch
 
+  // x tile: wave w stages rows w, w+NW, ...; a lane covers columns lane, lane+64, ...  All offsets inside one
+  // batch item are 32-bit (host checks C*T < 2^31).  Loads are UNCONDITIONAL on a clamped address (so they issue
+  // back to back with one wait at the LDS store); out-of-range elements are zeroed by a select afterwards.
   auto load_x = [&](int sg, int chunk) {
-    const SegArgs& s = a.seg[sg];
-    const int wx = BN + (s.taps - 1) * s.dil;
-    const float* xb = s.x + (int64_t)b * s.bstride;
-    const int64_t lim = s.in_len ? min(s.in_len[lb], s.Tin) : s.Tin;
-    const int64_t tau0 = q0 * s.tstride + s.toff - s.pad_left;
+    const float* xb = a.seg[sg].x + (int64_t)b * a.seg[sg].bstride;
+    const int taps = a.seg[sg].taps, dil = a.seg[sg].dil, tstride = a.seg[sg].tstride, Cin = a.seg[sg].Cin;
+    const int wx = BN + (taps - 1) * dil;
+    const int tin = (int)a.seg[sg].Tin;
+    const int lim = a.seg[sg].in_len ? min((int)min(a.seg[sg].in_len[lb], (int64_t)tin), tin) : tin;
+    const int tau0 = q0 * tstride + a.seg[sg].toff - a.seg[sg].pad_left;
+    const int cs = (int)a.seg[sg].cstride;
 #pragma unroll
-    for (int it = 0; it < XL; ++it) {
-      const int i = tid + it * NTHR;
-      const int r = i / XS, j = i - r * XS;
+    for (int rr = 0; rr < RW; ++rr) {
+      const int r = wave + rr * NW;
       const int ci = chunk * kCK + r;
-      const int64_t tau = tau0 + (int64_t)j * s.tstride;
-      float v = 0.f;
-      if (i < kCK * XS && j < wx && ci < s.Cin && tau >= 0 && tau < lim) v = xb[(int64_t)ci * s.cstride + tau] * s.in_scale;
-      xr[it] = v;
+      const bool rowok = (r < kCK) && (ci < Cin);
+      const float* xrow = xb + min(ci, Cin - 1) * cs;
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        const int j = lane + 64 * c;
+        const int tau = tau0 + j * tstride;
+        const bool ok = rowok && (j < wx) && (tau >= 0) && (tau < lim);
+        const float v = xrow[min(max(tau, 0), tin - 1)];
+        xr[rr][c] = ok ? v : 0.f;
+      }
     }
   };
-  auto store_x = [&](float* dst) {
+  auto store_x = [&](float* dst, float scale) {
 #pragma unroll
-    for (int it = 0; it < XL; ++it) {
-      const int i = tid + it * NTHR;
-      if (i < kCK * XS) dst[i] = xr[it];
+    for (int rr = 0; rr < RW; ++rr) {
+      const int r = wave + rr * NW;
+#pragma unroll
+      for (int c = 0; c < XC; ++c) {
+        const int j = lane + 64 * c;
+        if ((kCK % NW == 0 || r < kCK) && (XS % 64 == 0 || j < XS)) dst[r * XS + j] = xr[rr][c] * scale;
+      }
     }
   };
   auto load_w = [&](int step) {
     const float4* src = reinterpret_cast<const float4*>(wbase + (size_t)step * (kCK * BM));
-#pragma unroll
-    for (int it = 0; it < WL; ++it) {
-      const int i = tid + it * NTHR;
-      if (i < kCK * BM / 4) wr[it] = src[i];
-    }
+    constexpr int NW4 = kCK * BM / 4;
+    wr0 = src[NW4 % NTHR == 0 || NW4 >= NTHR ? tid : min(tid, NW4 - 1)];
+    if constexpr (WL == 2) wr1 = src[NW4 % NTHR == 0 ? tid + NTHR : min(tid + NTHR, NW4 - 1)];
   };
   auto store_w = [&](float* dst) {
-#pragma unroll
-    for (int it = 0; it < WL; ++it) {
-      const int i = tid + it * NTHR;
-      if (i < kCK * BM / 4) reinterpret_cast<float4*>(dst)[i] = wr[it];
+    constexpr int NW4 = kCK * BM / 4;
+    if (NW4 >= NTHR || tid < NW4) reinterpret_cast<float4*>(dst)[tid] = wr0;
+    if constexpr (WL == 2) {
+      if (NW4 % NTHR == 0 || tid + NTHR < NW4) reinterpret_cast<float4*>(dst)[tid + NTHR] = wr1;
     }
   };
 
   int sg = 0, chunk = 0, tap = 0, xbuf = 0;
   load_x(0, 0);
   load_w(0);
-  store_x(Xs);
+  store_x(Xs, a.seg[0].in_scale);
   store_w(Ws);
   __syncthreads();
 
@@ -166,7 +180,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
     }
     if (has_next) {
       store_w(Ws + ((s + 1) & 1) * (kCK * BM));
-      if (newx) store_x(Xs + (xbuf ^ 1) * (kCK * XS));
+      if (newx) store_x(Xs + (xbuf ^ 1) * (kCK * XS), a.seg[nsg].in_scale);
     }
     __syncthreads();
     if (newx) xbuf ^= 1;
@@ -174,47 +188,71 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
   }
 
   // ------------------------------------------------------------------ epilogue
-  const int64_t olim = a.out_len ? a.out_len[lb] : (int64_t)1 << 62;
+  // Lane (h, l31) holds, for each 32x32 tile, column l31 and rows (r&3) + 8*(r>>2) + 4*h, r = 0..15.
+  // Row-only quantities (bias, row offsets, channel map) are computed once per row, outside the column loop.
+  const int colbase = q0 + wave_n * (NT * 32) + l31;
+  const int tcols = (int)a.Tcols;
+  if (MODE == EPI_LINEAR) {
+    const int olim = a.out_len ? (int)min(a.out_len[lb], (int64_t)0x7fffffff) : 0x7fffffff;
+    float* yb = a.y + (int64_t)b * a.y_bs;
+    const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
+    const int ycs = (int)a.y_cs, rcs = (int)a.res_cs, tout = (int)a.Tout;
 #pragma unroll
-  for (int mi = 0; mi < MT; ++mi) {
-    const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;  // first packed row of this 32-row MFMA tile
+    for (int mi = 0; mi < MT; ++mi) {
+      const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-      const int64_t q = q0 + wave_n * (NT * 32) + ni * 32 + l31;
-      if (q >= a.Tcols) continue;
-      if (a.mode == EPI_LINEAR) {
+      for (int r = 0; r < 16; ++r) {
+        const int m = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
+        int ph = 0, co = m;
+        if (a.phases > 1) { ph = m / a.RP; co = m - ph * a.RP; }
+        if (co >= a.C || ph >= a.phases) continue;
+        const float bias = a.bias[m];
+        const float rs = a.row_scale ? a.row_scale[co] : 1.f;
+        const int tph = a.phase_base + ph;
+        float* yrow = yb + co * ycs;
+        const float* rrow = rb ? rb + co * rcs : nullptr;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int ph = m / a.RP, co = m - ph * a.RP;
-          if (co >= a.C || ph >= a.phases) continue;
-          const int64_t t = q * a.out_tstride + a.phase_base + ph;
-          if (t >= a.Tout) continue;
-          float v = act_apply(acc[mi][ni][r] + a.bias[m], a.act);
-          if (a.row_scale) v *= a.row_scale[co];
-          if (a.res) v += a.res[(int64_t)b * a.res_bs + (int64_t)co * a.res_cs + t];
-          float* yp = a.y + (int64_t)b * a.y_bs + (int64_t)co * a.y_cs + t;
-          if (a.accumulate) v += *yp;
+        for (int ni = 0; ni < NT; ++ni) {
+          const int q = colbase + ni * 32;
+          const int t = q * a.out_tstride + tph;
+          if (q >= tcols || t >= tout) continue;
+          float v = act_apply(acc[mi][ni][r] + bias, a.act) * rs;
+          if (rrow) v += rrow[t];
+          if (a.accumulate) v += yrow[t];
           if (a.out_div != 1.f) v = v / a.out_div;
           if (t >= olim) v = 0.f;
-          *yp = v;
+          yrow[t] = v;
         }
-      } else {
-        const int q32 = mtile >> 5;
+      }
+    }
+  } else {
+    float* yb = a.y + (int64_t)b * a.y_bs;
+    float* sb = (MODE == EPI_RESSKIP) ? a.skip + (int64_t)b * a.y_bs : nullptr;
+    const int ycs = (int)a.y_cs;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          if ((r >> 2) & 1) continue;  // odd 4-groups are the partner rows
-          const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
-          const int c = q32 * 16 + ((rho >> 3) >> 1) * 8 + (rho & 7);
-          if (c >= a.C) continue;
-          const float v0 = acc[mi][ni][r] + a.bias[mtile + rho];
-          const float v1 = acc[mi][ni][r + 4] + a.bias[mtile + rho + 8];
-          const int64_t off = (int64_t)b * a.y_bs + (int64_t)c * a.y_cs + q;
-          if (a.mode == EPI_GATE) {
-            a.y[off] = (1.f / (1.f + expf(-v0))) * tanhf(v1);
+    for (int mi = 0; mi < MT; ++mi) {
+      const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;
+      const int q32 = mtile >> 5;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((r >> 2) & 1) continue;  // odd 4-groups are the partner rows (filter / skip)
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int c = q32 * 16 + ((rho >> 3) >> 1) * 8 + (rho & 7);
+        if (c >= a.C) continue;
+        const float b0 = a.bias[mtile + rho], b1 = a.bias[mtile + rho + 8];
+        float* yrow = yb + c * ycs;
+        float* srow = (MODE == EPI_RESSKIP) ? sb + c * ycs : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int q = colbase + ni * 32;
+          if (q >= tcols) continue;
+          const float v0 = acc[mi][ni][r] + b0;
+          const float v1 = acc[mi][ni][(r + 4) & 15] + b1;
+          if (MODE == EPI_GATE) {
+            yrow[q] = (1.f / (1.f + expf(-v0))) * tanhf(v1);
           } else {
-            a.y[off] = (a.y[off] + v0) / 1.41421356237309504880f;
-            a.skip[off] = a.skip_first ? v1 : a.skip[off] + v1;
+            yrow[q] = (yrow[q] + v0) / 1.41421356237309504880f;
+            srow[q] = a.skip_first ? v1 : srow[q] + v1;
           }
         }
       }
@@ -222,7 +260,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
   }
 }
 
-template <int WM, int WN, int MT, int NT> static int launch_t(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KArgs& ka, int B, int mblocks, hipStream_t st) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   const size_t lds = (size_t)(2 * kCK * (BN + 64) + 2 * kCK * BM) * sizeof(float);
   dim3 grid((unsigned)((ka.Tcols + BN - 1) / BN), (unsigned)mblocks, (unsigned)B);
@@ -230,10 +268,12 @@ template <int WM, int WN, int MT, int NT> static int launch_t(const KArgs& ka, i
     set_error("conv_igemm: grid too large (mblocks %u, batch %u)", grid.y, grid.z);
     return DMEL_EINVAL;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT>), grid, dim3(64 * WM * WN), lds, st, ka);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, MODE>), grid, dim3(64 * WM * WN), lds, st, ka);
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
 }
+
+template <int MODE> static int launch_mode(const KArgs& ka, int BM, int B, int mblocks, hipStream_t st);
 
 static int pick_bn(int64_t T, std::initializer_list<int> cands) {
   int best = 0;
@@ -261,6 +301,8 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     o.Cin = sd.Cin; o.nchunk = (sd.Cin + kCK - 1) / kCK; o.taps = sd.taps; o.dil = sd.dil;
     o.pad_left = sd.pad_left; o.tstride = sd.tstride; o.toff = sd.toff;
     max_halo = std::max(max_halo, (sd.taps - 1) * sd.dil);
+    DMEL_CHECK_ARG((int64_t)sd.Cin * o.cstride < ((int64_t)1 << 31) && o.Tin * sd.tstride < ((int64_t)1 << 30),
+                   "conv: one batch item of the input exceeds 32-bit offsets");
   }
   if (max_halo > 64) {
     set_error("conv_igemm: receptive field (taps-1)*dilation = %d exceeds the 64-sample LDS halo", max_halo);
@@ -275,25 +317,35 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   ka.y = r.y; ka.y_bs = r.y_bs; ka.y_cs = r.y_cs; ka.Tout = r.Tout > 0 ? r.Tout : r.Tcols * r.out_tstride;
   ka.res = r.res; ka.res_bs = r.res_bs; ka.res_cs = r.res_cs; ka.row_scale = r.row_scale;
   ka.out_len = r.out_len; ka.skip = r.skip;
+  DMEL_CHECK_ARG((int64_t)d.C * ka.y_cs < ((int64_t)1 << 31) && ka.Tout < ((int64_t)1 << 30) && ka.Tcols < ((int64_t)1 << 30),
+                 "conv: one batch item of the output exceeds 32-bit offsets");
   const int mblocks = pc.Mpad / pc.BM;
   const double rows_real = (d.mode == EPI_LINEAR ? (double)d.C * d.phases : 2.0 * d.C);
   ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, 0.0);
-  switch (pc.BM) {
+  switch (d.mode) {
+    case EPI_LINEAR: return launch_mode<EPI_LINEAR>(ka, pc.BM, r.B, mblocks, stream);
+    case EPI_GATE: return launch_mode<EPI_GATE>(ka, pc.BM, r.B, mblocks, stream);
+    default: return launch_mode<EPI_RESSKIP>(ka, pc.BM, r.B, mblocks, stream);
+  }
+}
+
+template <int MODE> static int launch_mode(const KArgs& ka, int BM, int B, int mblocks, hipStream_t st) {
+  switch (BM) {
     case 128:
-      switch (pick_bn(r.Tcols, {128, 96})) {
-        case 128: return launch_t<2, 2, 2, 2>(ka, r.B, mblocks, stream);
-        default: return launch_t<4, 1, 1, 3>(ka, r.B, mblocks, stream);
+      switch (pick_bn(ka.Tcols, {128, 96})) {
+        case 128: return launch_t<2, 2, 2, 2, MODE>(ka, B, mblocks, st);
+        default: return launch_t<4, 1, 1, 3, MODE>(ka, B, mblocks, st);
       }
     case 64:
-      switch (pick_bn(r.Tcols, {128, 96})) {
-        case 128: return launch_t<2, 2, 1, 2>(ka, r.B, mblocks, stream);
-        default: return launch_t<2, 1, 1, 3>(ka, r.B, mblocks, stream);
+      switch (pick_bn(ka.Tcols, {128, 96})) {
+        case 128: return launch_t<2, 2, 1, 2, MODE>(ka, B, mblocks, st);
+        default: return launch_t<2, 1, 1, 3, MODE>(ka, B, mblocks, st);
       }
     default:
-      switch (pick_bn(r.Tcols, {256, 128, 96})) {
-        case 256: return launch_t<1, 4, 1, 2>(ka, r.B, mblocks, stream);
-        case 128: return launch_t<1, 4, 1, 1>(ka, r.B, mblocks, stream);
-        default: return launch_t<1, 3, 1, 1>(ka, r.B, mblocks, stream);
+      switch (pick_bn(ka.Tcols, {256, 128, 96})) {
+        case 256: return launch_t<1, 4, 1, 2, MODE>(ka, B, mblocks, st);
+        case 128: return launch_t<1, 4, 1, 1, MODE>(ka, B, mblocks, st);
+        default: return launch_t<1, 3, 1, 1, MODE>(ka, B, mblocks, st);
       }
   }
 }
