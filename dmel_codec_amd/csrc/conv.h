@@ -29,7 +29,7 @@ struct PackDesc {
 
 struct PackedConv {
   PackDesc d;
-  int BM = 0, Mpad = 0, steps = 0, RP = 0;
+  int Mpad = 0, steps = 0, RP = 0;   // Mpad: packed rows, multiple of 32
   double k_real = 0;       // sum over segments of Cin*taps (algorithmic reduction length)
   DevBuf w, bias;
 };
@@ -68,16 +68,6 @@ struct ConvRun {
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream);
 
 // ---- host packing (template, header-only) ---------------------------------------------------
-inline int choose_bm(int M) {
-  // Largest tile whose zero-row padding stays under ~12 %: big tiles reuse each staged x row across more
-  // output rows; a few dead rows are far cheaper than 32-row tiles on a 1000-row GEMM.
-  for (int bm : {128, 64}) {
-    const int p = (int)align_up(M, bm);
-    if ((p - M) * 8 <= M) return bm;
-  }
-  return 32;
-}
-
 template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, FW get_w, FB get_b) {
   pc.d = d;
   const bool paired = d.mode != EPI_LINEAR;
@@ -89,8 +79,7 @@ template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, F
     pc.RP = d.phases > 1 ? (int)align_up(d.C, 32) : d.C;
     M = pc.RP * d.phases;
   }
-  pc.BM = choose_bm(M);
-  pc.Mpad = (int)align_up(M, pc.BM);
+  pc.Mpad = (int)align_up(M, 32);
   pc.steps = 0;
   pc.k_real = 0;
   for (int s = 0; s < d.nseg; ++s) {
@@ -109,13 +98,15 @@ template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, F
     if (co >= d.C) return -1;
     return ph * d.C + co;
   };
-  const int mblocks = pc.Mpad / pc.BM;
+  // Weight image in MFMA A-fragment order: [32-row tile][K step][half][lane 0..63][4].  Lane l = 32*h + r holds,
+  // for half hf and j = 0..3, W[row 32*tile + r][k = 2*(4*hf + j) + h] of the step's 16 reduction rows, so a wave
+  // fetches a step's fragments with two fully coalesced 1 KiB dwordx4 loads and no LDS round trip.
   std::vector<float> w((size_t)pc.Mpad * pc.steps * kCK, 0.f), b(pc.Mpad, 0.f);
   for (int m = 0; m < pc.Mpad; ++m) {
     int sr = src_row(m);
     if (sr < 0) continue;
     b[m] = get_b(sr);
-    int mb = m / pc.BM, mi = m % pc.BM;
+    const int tile = m >> 5, r = m & 31;
     int step = 0;
     for (int s = 0; s < d.nseg; ++s) {
       const SegDesc& sd = d.seg[s];
@@ -125,11 +116,11 @@ template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, F
           for (int k = 0; k < kCK; ++k) {
             int ci = ch * kCK + k;
             if (ci >= sd.Cin) continue;
-            w[(((size_t)mb * pc.steps + step) * kCK + k) * pc.BM + mi] = get_w(s, sr, ci, tp);
+            const int h = k & 1, kk = k >> 1, hf = kk >> 2, j = kk & 3, lane = 32 * h + r;
+            w[((((size_t)tile * pc.steps + step) * 2 + hf) * 64 + lane) * 4 + j] = get_w(s, sr, ci, tp);
           }
     }
   }
-  (void)mblocks;
   DMEL_TRY(pc.w.upload(w.data(), w.size() * sizeof(float)));
   DMEL_TRY(pc.bias.upload(b.data(), b.size() * sizeof(float)));
   return DMEL_OK;

@@ -17,6 +17,9 @@
 // from ATen only by summation order.
 #include "conv.h"
 
+#include <cmath>
+#include <cstdlib>
+
 namespace dmel {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -31,7 +34,7 @@ struct SegArgs {
 
 struct KArgs {
   SegArgs seg[2];
-  int nseg, steps;
+  int nseg, steps, mtiles;
   const float* w;
   const float* bias;
   int64_t Tcols;
@@ -58,14 +61,12 @@ __device__ __forceinline__ float act_apply(float v, int act) {
 
 template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArgs a) {
-  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NW = WAVES_M * WAVES_N, NTHR = 64 * NW;
+  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NW = WAVES_M * WAVES_N;
   constexpr int XS = BN + 64;                      // staged x row: BN columns + up to 64 halo
   constexpr int RW = (kCK + NW - 1) / NW;          // x rows staged per wave
   constexpr int XC = (XS + 63) / 64;               // 64-column groups per x row
-  constexpr int WL = (kCK * BM / 4 + NTHR - 1) / NTHR;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Xs = smem;                  // [2][kCK][XS]
-  float* Ws = smem + 2 * kCK * XS;   // [2][kCK][BM]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
@@ -82,10 +83,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-  const float* wbase = a.w + (size_t)mblk * a.steps * (kCK * BM);
+  // A fragments come straight from global memory in lane order (conv.h, pack_conv): per 32-row tile and K step two
+  // coalesced float4 loads per lane, prefetched one step ahead into registers.  Tiles past the end (M not a multiple
+  // of BM) are clamped: the wave then recomputes the last tile and its epilogue is masked off.
+  const float4* wA[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int tile = min(mblk * (BM / 32) + wave_m * MT + mi, a.mtiles - 1);
+    wA[mi] = reinterpret_cast<const float4*>(a.w) + (size_t)tile * a.steps * 128 + lane;
+  }
+  float4 ac0[MT], ac1[MT], an0[MT], an1[MT];
   float xr[RW][XC];
-  static_assert(WL <= 2, "weight staging assumes at most two float4 per thread");
-  float4 wr0 = make_float4(0.f, 0.f, 0.f, 0.f), wr1 = wr0;  // named scalars: an indexed float4 array lands in scratch
 
   // x tile: wave w stages rows w, w+NW, ...; a lane covers columns lane, lane+64, ...  All offsets inside one
   // batch item are 32-bit (host checks C*T < 2^31).  Loads are UNCONDITIONAL on a clamped address (so they issue
@@ -125,25 +133,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
       }
     }
   };
-  auto load_w = [&](int step) {
-    const float4* src = reinterpret_cast<const float4*>(wbase + (size_t)step * (kCK * BM));
-    constexpr int NW4 = kCK * BM / 4;
-    wr0 = src[NW4 % NTHR == 0 || NW4 >= NTHR ? tid : min(tid, NW4 - 1)];
-    if constexpr (WL == 2) wr1 = src[NW4 % NTHR == 0 ? tid + NTHR : min(tid + NTHR, NW4 - 1)];
-  };
-  auto store_w = [&](float* dst) {
-    constexpr int NW4 = kCK * BM / 4;
-    if (NW4 >= NTHR || tid < NW4) reinterpret_cast<float4*>(dst)[tid] = wr0;
-    if constexpr (WL == 2) {
-      if (NW4 % NTHR == 0 || tid + NTHR < NW4) reinterpret_cast<float4*>(dst)[tid + NTHR] = wr1;
-    }
-  };
 
   int sg = 0, chunk = 0, tap = 0, xbuf = 0;
   load_x(0, 0);
-  load_w(0);
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) { ac0[mi] = wA[mi][0]; ac1[mi] = wA[mi][64]; }
   store_x(Xs, a.seg[0].in_scale);
-  store_w(Ws);
   __syncthreads();
 
   for (int s = 0; s < a.steps; ++s) {
@@ -157,20 +152,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
     }
     const bool has_next = s + 1 < a.steps;
     if (has_next) {
-      load_w(s + 1);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        an0[mi] = wA[mi][(size_t)(s + 1) * 128];
+        an1[mi] = wA[mi][(size_t)(s + 1) * 128 + 64];
+      }
       if (newx) load_x(nsg, nchunk);
     }
     {
-      const float* wp = Ws + (s & 1) * (kCK * BM) + wave_m * (MT * 32) + l31;
-      const float* xp = Xs + xbuf * (kCK * XS) + wave_n * (NT * 32) + l31 + tap * a.seg[sg].dil;
+      const float* xp = Xs + xbuf * (kCK * XS) + wave_n * (NT * 32) + l31 + tap * a.seg[sg].dil + h * XS;
 #pragma unroll
       for (int kk = 0; kk < kCK / 2; ++kk) {
-        const int k = 2 * kk + h;
         float av[MT], bv[NT];
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) av[mi] = wp[k * BM + mi * 32];
+        for (int mi = 0; mi < MT; ++mi) {
+          const float4 q = (kk < 4) ? ac0[mi] : ac1[mi];
+          av[mi] = (kk & 3) == 0 ? q.x : (kk & 3) == 1 ? q.y : (kk & 3) == 2 ? q.z : q.w;
+        }
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) bv[ni] = xp[k * XS + ni * 32];
+        for (int ni = 0; ni < NT; ++ni) bv[ni] = xp[2 * kk * XS + ni * 32];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -179,11 +179,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
       }
     }
     if (has_next) {
-      store_w(Ws + ((s + 1) & 1) * (kCK * BM));
-      if (newx) store_x(Xs + (xbuf ^ 1) * (kCK * XS), a.seg[nsg].in_scale);
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) { ac0[mi] = an0[mi]; ac1[mi] = an1[mi]; }
+      if (newx) {   // the only synchronisation: once per 16-channel chunk, when the other x buffer is published
+        store_x(Xs + (xbuf ^ 1) * (kCK * XS), a.seg[nsg].in_scale);
+        __syncthreads();
+        xbuf ^= 1;
+      }
     }
-    __syncthreads();
-    if (newx) xbuf ^= 1;
     sg = nsg; chunk = nchunk; tap = ntap;
   }
 
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;
+      if (mtile >= a.mtiles * 32) continue;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int m = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -232,6 +236,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;
+      if (mtile >= a.mtiles * 32) continue;
       const int q32 = mtile >> 5;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -261,8 +266,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
 }
 
 template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KArgs& ka, int B, int mblocks, hipStream_t st) {
-  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  const size_t lds = (size_t)(2 * kCK * (BN + 64) + 2 * kCK * BM) * sizeof(float);
+  constexpr int BN = WN * NT * 32;
+  const size_t lds = (size_t)(2 * kCK * (BN + 64)) * sizeof(float);
   dim3 grid((unsigned)((ka.Tcols + BN - 1) / BN), (unsigned)mblocks, (unsigned)B);
   if (grid.y > 65535 || grid.z > 65535) {
     set_error("conv_igemm: grid too large (mblocks %u, batch %u)", grid.y, grid.z);
@@ -273,16 +278,55 @@ template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KA
   return DMEL_OK;
 }
 
-template <int MODE> static int launch_mode(const KArgs& ka, int BM, int B, int mblocks, hipStream_t st);
+// ---- tile selection -------------------------------------------------------------------------------------------
+// The kernel is MFMA-bound, so a launch costs (rounds of workgroups over the 256 CUs) x (tile area) / (how well a wave
+// of that shape keeps the pipe fed).  Padding waste and the last, partly filled round are what the choice trades.
+struct TileCfg {
+  int wm, wn, mt, nt;
+  float eff;
+};
+static const TileCfg kTiles[] = {
+    {2, 2, 2, 2, 1.00f},  // 128 x 128, 4 waves
+    {4, 1, 1, 3, 0.95f},  // 128 x  96
+    {2, 2, 1, 2, 0.92f},  //  64 x 128
+    {2, 1, 1, 3, 0.85f},  //  64 x  96, 2 waves
+    {1, 4, 1, 2, 0.90f},  //  32 x 256
+    {1, 4, 1, 1, 0.80f},  //  32 x 128
+    {1, 3, 1, 1, 0.80f},  //  32 x  96, 3 waves
+};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
-static int pick_bn(int64_t T, std::initializer_list<int> cands) {
+static int pick_tile(int mtiles, int64_t T, int B) {
+  static int forced = [] {
+    const char* e = getenv("DMEL_CONV_TILE");
+    return e ? atoi(e) : -1;
+  }();
+  if (forced >= 0 && forced < kNumTiles) return forced;
   int best = 0;
-  int64_t best_cols = 0;
-  for (int bn : cands) {
-    int64_t cols = (T + bn - 1) / bn * bn;
-    if (best == 0 || cols < best_cols || (cols == best_cols && bn > best)) { best = bn; best_cols = cols; }
+  double best_cost = 1e300;
+  for (int i = 0; i < kNumTiles; ++i) {
+    const int bm = kTiles[i].wm * kTiles[i].mt * 32, bn = kTiles[i].wn * kTiles[i].nt * 32;
+    const double wgs = (double)((mtiles * 32 + bm - 1) / bm) * (double)((T + bn - 1) / bn) * B;
+    const double rounds = std::ceil(wgs / 256.0);
+    // above ~4 rounds the partly filled last round stops mattering
+    const double cost = (wgs > 1024 ? wgs / 256.0 : rounds) * bm * bn / kTiles[i].eff;
+    if (cost < best_cost) { best_cost = cost; best = i; }
   }
   return best;
+}
+
+template <int MODE> static int launch_mode(const KArgs& ka, int tile, int B, hipStream_t st) {
+  const TileCfg& t = kTiles[tile];
+  const int mblocks = (ka.mtiles * 32 + t.wm * t.mt * 32 - 1) / (t.wm * t.mt * 32);
+  switch (tile) {
+    case 0: return launch_t<2, 2, 2, 2, MODE>(ka, B, mblocks, st);
+    case 1: return launch_t<4, 1, 1, 3, MODE>(ka, B, mblocks, st);
+    case 2: return launch_t<2, 2, 1, 2, MODE>(ka, B, mblocks, st);
+    case 3: return launch_t<2, 1, 1, 3, MODE>(ka, B, mblocks, st);
+    case 4: return launch_t<1, 4, 1, 2, MODE>(ka, B, mblocks, st);
+    case 5: return launch_t<1, 4, 1, 1, MODE>(ka, B, mblocks, st);
+    default: return launch_t<1, 3, 1, 1, MODE>(ka, B, mblocks, st);
+  }
 }
 
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
@@ -319,34 +363,14 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   ka.out_len = r.out_len; ka.skip = r.skip;
   DMEL_CHECK_ARG((int64_t)d.C * ka.y_cs < ((int64_t)1 << 31) && ka.Tout < ((int64_t)1 << 30) && ka.Tcols < ((int64_t)1 << 30),
                  "conv: one batch item of the output exceeds 32-bit offsets");
-  const int mblocks = pc.Mpad / pc.BM;
+  ka.mtiles = pc.Mpad / 32;
   const double rows_real = (d.mode == EPI_LINEAR ? (double)d.C * d.phases : 2.0 * d.C);
   ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, 0.0);
+  const int tile = pick_tile(ka.mtiles, r.Tcols, r.B);
   switch (d.mode) {
-    case EPI_LINEAR: return launch_mode<EPI_LINEAR>(ka, pc.BM, r.B, mblocks, stream);
-    case EPI_GATE: return launch_mode<EPI_GATE>(ka, pc.BM, r.B, mblocks, stream);
-    default: return launch_mode<EPI_RESSKIP>(ka, pc.BM, r.B, mblocks, stream);
-  }
-}
-
-template <int MODE> static int launch_mode(const KArgs& ka, int BM, int B, int mblocks, hipStream_t st) {
-  switch (BM) {
-    case 128:
-      switch (pick_bn(ka.Tcols, {128, 96})) {
-        case 128: return launch_t<2, 2, 2, 2, MODE>(ka, B, mblocks, st);
-        default: return launch_t<4, 1, 1, 3, MODE>(ka, B, mblocks, st);
-      }
-    case 64:
-      switch (pick_bn(ka.Tcols, {128, 96})) {
-        case 128: return launch_t<2, 2, 1, 2, MODE>(ka, B, mblocks, st);
-        default: return launch_t<2, 1, 1, 3, MODE>(ka, B, mblocks, st);
-      }
-    default:
-      switch (pick_bn(ka.Tcols, {256, 128, 96})) {
-        case 256: return launch_t<1, 4, 1, 2, MODE>(ka, B, mblocks, st);
-        case 128: return launch_t<1, 4, 1, 1, MODE>(ka, B, mblocks, st);
-        default: return launch_t<1, 3, 1, 1, MODE>(ka, B, mblocks, st);
-      }
+    case EPI_LINEAR: return launch_mode<EPI_LINEAR>(ka, tile, r.B, stream);
+    case EPI_GATE: return launch_mode<EPI_GATE>(ka, tile, r.B, stream);
+    default: return launch_mode<EPI_RESSKIP>(ka, tile, r.B, stream);
   }
 }
 
