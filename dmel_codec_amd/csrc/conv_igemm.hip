@@ -286,8 +286,8 @@ struct TileCfg {
   float eff;
 };
 static const TileCfg kTiles[] = {
-    {2, 2, 2, 2, 1.00f},  // 128 x 128, 4 waves
-    {4, 1, 1, 3, 0.95f},  // 128 x  96
+    {2, 2, 2, 2, 0.93f},  // 128 x 128, 4 waves (212 registers: 2 waves per SIMD)
+    {4, 1, 1, 3, 1.00f},  // 128 x  96 (164 registers: 3 waves per SIMD), measured fastest per MFMA
     {2, 2, 1, 2, 0.92f},  //  64 x 128
     {2, 1, 1, 3, 0.85f},  //  64 x  96, 2 waves
     {1, 4, 1, 2, 0.90f},  //  32 x 256

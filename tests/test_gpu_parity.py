@@ -274,6 +274,19 @@ def test_bigvgan_golden(dev, golden):
     assert rel_err(y, g.outs["audio"]) < TOL
 
 
+def assert_close_to_truth(y, ref32, ref64, what=""):
+    """Deep random-weight stacks amplify rounding noise: the fp32 oracle itself moves by 3-5e-5 relative when only
+    its thread count (oneDNN blocking) changes.  So whole-network outputs are judged against the SAME oracle run in
+    float64: the kernel must be within 1e-4 of the truth or within 3x the fp32 oracle's own distance from it."""
+    e_gpu, e_ref = rel_err(y, ref64), rel_err(ref32, ref64)
+    assert e_gpu < max(TOL, 3.0 * e_ref), f"{what}: gpu-vs-fp64 {e_gpu:.2e}, oracle-fp32-vs-fp64 {e_ref:.2e}"
+    assert rel_err(y, ref32) < 3.0 * TOL, what
+
+
+def to64(sd):
+    return {k: v.double() for k, v in sd.items()}
+
+
 def test_bigvgan_base_config(dev):
     """BigVGAN-base (BASELINE config 2 vocoder, 14 M parameters) on a short mel against the oracle."""
     from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
@@ -283,10 +296,12 @@ def test_bigvgan_base_config(dev):
     m = BigVGAN(h)
     randomise(m, 12, scale=0.7)
     mel = torch.randn(2, 80, 12)
-    ref = ref_cpu.bigvgan_forward(cpu_sd(m), dict(h), mel)
+    sd = cpu_sd(m)
+    ref = ref_cpu.bigvgan_forward(sd, dict(h), mel)
+    ref64 = ref_cpu.bigvgan_forward(to64(sd), dict(h), mel.double())
     y = m.to(dev)(mel.to(dev))
     assert y.shape == ref.shape == (2, 1, 12 * 256)
-    assert rel_err(y, ref) < TOL
+    assert_close_to_truth(y, ref, ref64, "bigvgan-base")
 
 
 # ------------------------------------------------------------------------------------ whole codec
@@ -351,7 +366,8 @@ def test_codec_decode_waveform(dev):
     audio, mel = codec.decode(ids.to(dev), flen.to(dev), return_audios=True, noise=noise.to(dev))
     assert mel.shape == mel_ref.shape and audio.shape == audio_ref.shape == (B, 1, T4 * 4 * 256)
     assert rel_err(mel, mel_ref) < TOL
-    assert rel_err(audio, audio_ref) < TOL
+    audio64, _ = ref_cpu.vqgan_decode(to64(sd), cfg, ids, flen, noise.double(), to64(voc_sd), dict(codec.vocoder.h))
+    assert_close_to_truth(audio, audio_ref, audio64, "decode waveform")
     z_ref, _ = ref_cpu.vqgan_quantized_features(sd, cfg, ids, flen)
     z, _ = codec.get_quantized_features_from_indices(ids.to(dev), flen.to(dev))
     assert rel_err(z, z_ref) < TOL
