@@ -12,7 +12,7 @@ from typing import Optional, Sequence
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmel_hip.so")
+LIB_PATH = os.environ.get("DMEL_LIB") or os.path.join(_HERE, "libdmel_hip.so")   # DMEL_LIB: A/B builds in tools/
 _lib: Optional[C.CDLL] = None
 
 i64p = C.POINTER(C.c_int64)

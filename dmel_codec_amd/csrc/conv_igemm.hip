@@ -59,10 +59,12 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
-template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE>
+// HALO = 64: any (taps-1)*dilation <= 64.  HALO = 0: every segment is 1-tap (pointwise convs, Linear layers): a
+// third less staging work and LDS, which buys those launch-bound kernels a wave of occupancy.
+template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArgs a) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NW = WAVES_M * WAVES_N;
-  constexpr int XS = BN + 64;                      // staged x row: BN columns + up to 64 halo
+  constexpr int XS = BN + HALO;                    // staged x row: BN columns + halo
   constexpr int RW = (kCK + NW - 1) / NW;          // x rows staged per wave
   constexpr int XC = (XS + 63) / 64;               // 64-column groups per x row
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -265,17 +267,24 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
   }
 }
 
-template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+template <int WM, int WN, int MT, int NT, int MODE, int HALO>
+static int launch_h(const KArgs& ka, int B, int mblocks, hipStream_t st) {
   constexpr int BN = WN * NT * 32;
-  const size_t lds = (size_t)(2 * kCK * (BN + 64)) * sizeof(float);
+  const size_t lds = (size_t)(2 * kCK * (BN + HALO)) * sizeof(float);
   dim3 grid((unsigned)((ka.Tcols + BN - 1) / BN), (unsigned)mblocks, (unsigned)B);
   if (grid.y > 65535 || grid.z > 65535) {
     set_error("conv_igemm: grid too large (mblocks %u, batch %u)", grid.y, grid.z);
     return DMEL_EINVAL;
   }
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, MODE>), grid, dim3(64 * WM * WN), lds, st, ka);
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, MODE, HALO>), grid, dim3(64 * WM * WN), lds, st, ka);
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
+}
+
+template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+  bool pointwise = true;
+  for (int s = 0; s < ka.nseg; ++s) pointwise = pointwise && ka.seg[s].taps == 1;
+  return pointwise ? launch_h<WM, WN, MT, NT, MODE, 0>(ka, B, mblocks, st) : launch_h<WM, WN, MT, NT, MODE, 64>(ka, B, mblocks, st);
 }
 
 // ---- tile selection -------------------------------------------------------------------------------------------
