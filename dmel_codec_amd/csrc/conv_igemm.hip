@@ -59,6 +59,83 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   }
 }
 
+// ------------------------------------------------------------------ epilogue (shared by both kernels)
+// Lane (h, l31) holds, for each 32x32 tile, column l31 and rows (r&3) + 8*(r>>2) + 4*h, r = 0..15.
+// Row-only quantities (bias, row offsets, channel map) are computed once per row, outside the column loop.
+template <int MT, int NT, int MODE>
+__device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT][NT], int mrow0, int colbase, int b, int lb,
+                                              int h) {
+  const int tcols = (int)a.Tcols;
+  if (MODE == EPI_LINEAR) {
+    const int olim = a.out_len ? (int)min(a.out_len[lb], (int64_t)0x7fffffff) : 0x7fffffff;
+    float* yb = a.y + (int64_t)b * a.y_bs;
+    const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
+    const int ycs = (int)a.y_cs, rcs = (int)a.res_cs, tout = (int)a.Tout;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int mtile = mrow0 + mi * 32;
+      if (mtile >= a.mtiles * 32) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
+        int ph = 0, co = m;
+        if (a.phases > 1) { ph = m / a.RP; co = m - ph * a.RP; }
+        if (co >= a.C || ph >= a.phases) continue;
+        const float bias = a.bias[m];
+        const float rs = a.row_scale ? a.row_scale[co] : 1.f;
+        const int tph = a.phase_base + ph;
+        float* yrow = yb + co * ycs;
+        const float* rrow = rb ? rb + co * rcs : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int q = colbase + ni * 32;
+          const int t = q * a.out_tstride + tph;
+          if (q >= tcols || t >= tout) continue;
+          float v = act_apply(acc[mi][ni][r] + bias, a.act) * rs;
+          if (rrow) v += rrow[t];
+          if (a.accumulate) v += yrow[t];
+          if (a.out_div != 1.f) v = v / a.out_div;
+          if (t >= olim) v = 0.f;
+          yrow[t] = v;
+        }
+      }
+    }
+  } else {
+    float* yb = a.y + (int64_t)b * a.y_bs;
+    float* sb = (MODE == EPI_RESSKIP) ? a.skip + (int64_t)b * a.y_bs : nullptr;
+    const int ycs = (int)a.y_cs;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const int mtile = mrow0 + mi * 32;
+      if (mtile >= a.mtiles * 32) continue;
+      const int q32 = mtile >> 5;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if ((r >> 2) & 1) continue;  // odd 4-groups are the partner rows (filter / skip)
+        const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int c = q32 * 16 + ((rho >> 3) >> 1) * 8 + (rho & 7);
+        if (c >= a.C) continue;
+        const float b0 = a.bias[mtile + rho], b1 = a.bias[mtile + rho + 8];
+        float* yrow = yb + c * ycs;
+        float* srow = (MODE == EPI_RESSKIP) ? sb + c * ycs : nullptr;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) {
+          const int q = colbase + ni * 32;
+          if (q >= tcols) continue;
+          const float v0 = acc[mi][ni][r] + b0;
+          const float v1 = acc[mi][ni][(r + 4) & 15] + b1;
+          if (MODE == EPI_GATE) {
+            yrow[q] = (1.f / (1.f + expf(-v0))) * tanhf(v1);
+          } else {
+            yrow[q] = (yrow[q] + v0) / 1.41421356237309504880f;
+            srow[q] = a.skip_first ? v1 : srow[q] + v1;
+          }
+        }
+      }
+    }
+  }
+}
+
 // HALO = 64: any (taps-1)*dilation <= 64.  HALO = 0: every segment is 1-tap (pointwise convs, Linear layers): a
 // third less staging work and LDS, which buys those launch-bound kernels a wave of occupancy.
 template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO>
@@ -192,79 +269,128 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
     sg = nsg; chunk = nchunk; tap = ntap;
   }
 
-  // ------------------------------------------------------------------ epilogue
-  // Lane (h, l31) holds, for each 32x32 tile, column l31 and rows (r&3) + 8*(r>>2) + 4*h, r = 0..15.
-  // Row-only quantities (bias, row offsets, channel map) are computed once per row, outside the column loop.
-  const int colbase = q0 + wave_n * (NT * 32) + l31;
-  const int tcols = (int)a.Tcols;
-  if (MODE == EPI_LINEAR) {
-    const int olim = a.out_len ? (int)min(a.out_len[lb], (int64_t)0x7fffffff) : 0x7fffffff;
-    float* yb = a.y + (int64_t)b * a.y_bs;
-    const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
-    const int ycs = (int)a.y_cs, rcs = (int)a.res_cs, tout = (int)a.Tout;
+  conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
+}
+
+// -----------------------------------------------------------------------------------------------------------
+// Register-direct variant: no LDS, no barriers.  Every wave streams BOTH operands of its (32 MT) x (32 NT) tile from
+// global memory / L1 into double-buffered registers: A as in the kernel above, B one dword per lane and MFMA
+// (lanes 0-31: 32 consecutive time steps of channel k, lanes 32-63: of channel k+1 -- two 128-byte segments per
+// load).  A tap is a shifted re-read that hits L1.  Per K step a (1,1) wave issues 10 loads, 8 selects and ~15
+// integer instructions for its 8 MFMAs, against ~340 instructions in the LDS-staged kernel, whose x-tile staging and
+// barrier dominate when a wave owns few MFMAs per step: small-N WaveNet GEMMs, 32- and 64-channel BigVGAN stages.
+// Operand traffic at full MFMA rate is 16-32 B/clk/CU, within the 64 B/clk of L1.
+template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_direct_kernel(KArgs a) {
+  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int h = lane >> 5, l31 = lane & 31;
+  const int q0 = blockIdx.x * BN;
+  const int mblk = blockIdx.y, b = blockIdx.z;
+  const int lb = b / a.len_div;
+
+  floatx16 acc[MT][NT];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;
-      if (mtile >= a.mtiles * 32) continue;
+  for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
-        int ph = 0, co = m;
-        if (a.phases > 1) { ph = m / a.RP; co = m - ph * a.RP; }
-        if (co >= a.C || ph >= a.phases) continue;
-        const float bias = a.bias[m];
-        const float rs = a.row_scale ? a.row_scale[co] : 1.f;
-        const int tph = a.phase_base + ph;
-        float* yrow = yb + co * ycs;
-        const float* rrow = rb ? rb + co * rcs : nullptr;
+    for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-          const int q = colbase + ni * 32;
-          const int t = q * a.out_tstride + tph;
-          if (q >= tcols || t >= tout) continue;
-          float v = act_apply(acc[mi][ni][r] + bias, a.act) * rs;
-          if (rrow) v += rrow[t];
-          if (a.accumulate) v += yrow[t];
-          if (a.out_div != 1.f) v = v / a.out_div;
-          if (t >= olim) v = 0.f;
-          yrow[t] = v;
-        }
-      }
-    }
-  } else {
-    float* yb = a.y + (int64_t)b * a.y_bs;
-    float* sb = (MODE == EPI_RESSKIP) ? a.skip + (int64_t)b * a.y_bs : nullptr;
-    const int ycs = (int)a.y_cs;
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  const float4* wA[MT];
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-      const int mtile = mblk * BM + wave_m * (MT * 32) + mi * 32;
-      if (mtile >= a.mtiles * 32) continue;
-      const int q32 = mtile >> 5;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if ((r >> 2) & 1) continue;  // odd 4-groups are the partner rows (filter / skip)
-        const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int c = q32 * 16 + ((rho >> 3) >> 1) * 8 + (rho & 7);
-        if (c >= a.C) continue;
-        const float b0 = a.bias[mtile + rho], b1 = a.bias[mtile + rho + 8];
-        float* yrow = yb + c * ycs;
-        float* srow = (MODE == EPI_RESSKIP) ? sb + c * ycs : nullptr;
-#pragma unroll
-        for (int ni = 0; ni < NT; ++ni) {
-          const int q = colbase + ni * 32;
-          if (q >= tcols) continue;
-          const float v0 = acc[mi][ni][r] + b0;
-          const float v1 = acc[mi][ni][(r + 4) & 15] + b1;
-          if (MODE == EPI_GATE) {
-            yrow[q] = (1.f / (1.f + expf(-v0))) * tanhf(v1);
-          } else {
-            yrow[q] = (yrow[q] + v0) / 1.41421356237309504880f;
-            srow[q] = a.skip_first ? v1 : srow[q] + v1;
-          }
-        }
-      }
-    }
+  for (int mi = 0; mi < MT; ++mi) {
+    const int tile = min(mblk * (BM / 32) + wave_m * MT + mi, a.mtiles - 1);
+    wA[mi] = reinterpret_cast<const float4*>(a.w) + (size_t)tile * a.steps * 128 + lane;
   }
+  const int qcol = q0 + wave_n * (NT * 32) + l31;   // this lane's column of n-tile 0
+
+  float4 ac0[MT], ac1[MT], an0[MT], an1[MT];
+  float bc[NT][8], bn[NT][8];
+  int sbase = 0;   // global K-step index of the segment's first step
+
+  for (int sg = 0; sg < a.nseg; ++sg) {
+    const SegArgs& sa = a.seg[sg];
+    const float* xb = sa.x + (int64_t)b * sa.bstride;
+    const int taps = sa.taps, dil = sa.dil, cin = sa.Cin, cs = (int)sa.cstride, tin = (int)sa.Tin;
+    const int lim = sa.in_len ? min((int)min(sa.in_len[lb], (int64_t)tin), tin) : tin;
+    const float scale = sa.in_scale;
+    const int nst = sa.nchunk * taps;
+    int tcol[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) tcol[ni] = (qcol + ni * 32) * sa.tstride + sa.toff - sa.pad_left;
+    int rowoff[8];
+
+    // loads of local step (chunk, tap) into (A0, A1, B)
+#define DMEL_DIRECT_LOAD(A0, A1, B, chunk, tap, gstep)                                                  \
+    {                                                                                                   \
+      _Pragma("unroll") for (int mi = 0; mi < MT; ++mi) {                                               \
+        A0[mi] = wA[mi][(size_t)(gstep) * 128];                                                         \
+        A1[mi] = wA[mi][(size_t)(gstep) * 128 + 64];                                                    \
+      }                                                                                                 \
+      if ((tap) == 0) {                                                                                 \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk)                                                \
+          rowoff[kk] = min((chunk) * kCK + 2 * kk + h, cin - 1) * cs;                                   \
+      }                                                                                                 \
+      _Pragma("unroll") for (int ni = 0; ni < NT; ++ni) {                                               \
+        const int tau = tcol[ni] + (tap) * dil;                                                         \
+        const bool ok = (tau >= 0) && (tau < lim);                                                      \
+        const int tc = min(max(tau, 0), tin - 1);                                                       \
+        _Pragma("unroll") for (int kk = 0; kk < 8; ++kk) {                                              \
+          const float v = xb[rowoff[kk] + tc];                                                          \
+          B[ni][kk] = ok ? v * scale : 0.f;                                                             \
+        }                                                                                               \
+      }                                                                                                 \
+    }
+
+    int chunk = 0, tap = 0;
+    DMEL_DIRECT_LOAD(ac0, ac1, bc, 0, 0, sbase)
+    for (int ls = 0; ls < nst; ++ls) {
+      int ntap = tap + 1, nchunk = chunk;
+      if (ntap == taps) { ntap = 0; ++nchunk; }
+      const bool has_next = ls + 1 < nst;
+      if (has_next) DMEL_DIRECT_LOAD(an0, an1, bn, nchunk, ntap, sbase + ls + 1)
+#pragma unroll
+      for (int kk = 0; kk < 8; ++kk) {
+        float av[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+          const float4 q = (kk < 4) ? ac0[mi] : ac1[mi];
+          av[mi] = (kk & 3) == 0 ? q.x : (kk & 3) == 1 ? q.y : (kk & 3) == 2 ? q.z : q.w;
+        }
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mi], bc[ni][kk], acc[mi][ni], 0, 0, 0);
+      }
+      if (has_next) {
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) { ac0[mi] = an0[mi]; ac1[mi] = an1[mi]; }
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int kk = 0; kk < 8; ++kk) bc[ni][kk] = bn[ni][kk];
+      }
+      chunk = nchunk; tap = ntap;
+    }
+#undef DMEL_DIRECT_LOAD
+    sbase += nst;
+  }
+  conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), qcol, b, lb, h);
+}
+
+template <int WM, int WN, int MT, int NT, int MODE> static int launch_d(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+  constexpr int BN = WN * NT * 32;
+  dim3 grid((unsigned)((ka.Tcols + BN - 1) / BN), (unsigned)mblocks, (unsigned)B);
+  if (grid.y > 65535 || grid.z > 65535) {
+    set_error("conv_igemm: grid too large (mblocks %u, batch %u)", grid.y, grid.z);
+    return DMEL_EINVAL;
+  }
+  hipLaunchKernelGGL((conv_direct_kernel<WM, WN, MT, NT, MODE>), grid, dim3(64 * WM * WN), 0, st, ka);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
 }
 
 template <int WM, int WN, int MT, int NT, int MODE, int HALO>
@@ -302,6 +428,14 @@ static const TileCfg kTiles[] = {
     {1, 4, 1, 2, 0.90f},  //  32 x 256
     {1, 4, 1, 1, 0.80f},  //  32 x 128
     {1, 3, 1, 1, 0.80f},  //  32 x  96, 3 waves
+    // register-direct variants (conv_direct_kernel), ids 7..: not picked automatically yet
+    {1, 4, 1, 1, 0.00f},  //  7: 32 x 128, 4 waves
+    {1, 3, 1, 1, 0.00f},  //  8: 32 x  96, 3 waves
+    {1, 4, 1, 2, 0.00f},  //  9: 32 x 256
+    {2, 2, 1, 2, 0.00f},  // 10: 64 x 128
+    {4, 1, 1, 3, 0.00f},  // 11: 128 x 96
+    {2, 2, 2, 2, 0.00f},  // 12: 128 x 128
+    {2, 2, 1, 1, 0.00f},  // 13: 64 x 64
 };
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
@@ -311,9 +445,13 @@ static int pick_tile(int mtiles, int64_t T, int B) {
     return e ? atoi(e) : -1;
   }();
   if (forced >= 0 && forced < kNumTiles) return forced;
+  // One column tile per batch item (1 s clips through the WaveNets, conv_pre): too few workgroups for x-tile sharing
+  // through LDS to pay; the register-direct kernel measured 1.06-1.4x faster there (tools/ab_tiles.sh).
+  if (T <= 96 && mtiles >= 4) return 8;
   int best = 0;
   double best_cost = 1e300;
   for (int i = 0; i < kNumTiles; ++i) {
+    if (kTiles[i].eff <= 0.f) continue;
     const int bm = kTiles[i].wm * kTiles[i].mt * 32, bn = kTiles[i].wn * kTiles[i].nt * 32;
     const double wgs = (double)((mtiles * 32 + bm - 1) / bm) * (double)((T + bn - 1) / bn) * B;
     const double rounds = std::ceil(wgs / 256.0);
@@ -334,7 +472,14 @@ template <int MODE> static int launch_mode(const KArgs& ka, int tile, int B, hip
     case 3: return launch_t<2, 1, 1, 3, MODE>(ka, B, mblocks, st);
     case 4: return launch_t<1, 4, 1, 2, MODE>(ka, B, mblocks, st);
     case 5: return launch_t<1, 4, 1, 1, MODE>(ka, B, mblocks, st);
-    default: return launch_t<1, 3, 1, 1, MODE>(ka, B, mblocks, st);
+    case 6: return launch_t<1, 3, 1, 1, MODE>(ka, B, mblocks, st);
+    case 7: return launch_d<1, 4, 1, 1, MODE>(ka, B, mblocks, st);
+    case 8: return launch_d<1, 3, 1, 1, MODE>(ka, B, mblocks, st);
+    case 9: return launch_d<1, 4, 1, 2, MODE>(ka, B, mblocks, st);
+    case 10: return launch_d<2, 2, 1, 2, MODE>(ka, B, mblocks, st);
+    case 11: return launch_d<4, 1, 1, 3, MODE>(ka, B, mblocks, st);
+    case 12: return launch_d<2, 2, 2, 2, MODE>(ka, B, mblocks, st);
+    default: return launch_d<2, 2, 1, 1, MODE>(ka, B, mblocks, st);
   }
 }
 
