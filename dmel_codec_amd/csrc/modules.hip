@@ -2,6 +2,7 @@
 // Host code only: consumes reference state-dict tensors, folds weight norm, re-tiles weights for the MFMA conv
 // kernel and issues the kernel sequence of one forward on the caller's stream (no allocation, no sync).
 #include <cmath>
+#include <cstdlib>
 #include <map>
 #include <memory>
 
@@ -466,6 +467,22 @@ struct dmel_bigvgan {
   SnakeP act_post;
   float taps[12];
   int64_t total_up = 1;
+  // The AMP blocks of a stage are independent until their outputs are averaged: they run on the caller's stream plus
+  // up to two library-owned side streams, forked and joined with events around every stage, so the VALU-bound
+  // anti-alias activations of one block overlap the MFMA-bound convolutions of another.  Semantics on the caller's
+  // stream are unchanged (everything is ordered behind what was on it and finished when the final join is reached).
+  static constexpr int kSide = 2;
+  hipStream_t side[kSide] = {nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr}, ev_chain[3] = {nullptr, nullptr, nullptr};
+  bool multi = false;
+  ~dmel_bigvgan() {
+    for (int i = 0; i < kSide; ++i) {
+      if (side[i]) (void)hipStreamDestroy(side[i]);
+      if (ev_join[i]) (void)hipEventDestroy(ev_join[i]);
+    }
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    for (auto& e : ev_chain) if (e) (void)hipEventDestroy(e);
+  }
 };
 
 extern "C" int dmel_bigvgan_create(dmel_bigvgan** out, const dmel_bigvgan_config* cfg) {
@@ -597,6 +614,16 @@ extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
       for (int a = 0; a < 6; ++a) DMEL_TRY(load_snake(ab.act[a], m->ts, bp + "activations." + std::to_string(a) + ".", ch, snake));
     }
   }
+  if (!m->ev_fork) {
+    const char* e = getenv("DMEL_BIGVGAN_STREAMS");
+    m->multi = !(e && atoi(e) == 1) && c.num_kernels <= 3 && c.num_kernels > 1;
+    DMEL_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) DMEL_HIP(hipEventCreateWithFlags(&m->ev_chain[i], hipEventDisableTiming));
+    for (int i = 0; i < dmel_bigvgan::kSide; ++i) {
+      DMEL_HIP(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
+      DMEL_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
+    }
+  }
   DMEL_TRY(load_snake(m->act_post, m->ts, "activation_post.", ch, snake));
   DMEL_TRY(pack_same_conv(m->conv_post, m->ts, "conv_post.", 1, ch, 7, 1, c.use_bias_at_final != 0));
   m->ts.t.clear();
@@ -604,7 +631,15 @@ extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
   return DMEL_OK;
 }
 
-static size_t bigvgan_plan(const dmel_bigvgan* m, int B, int64_t T, void* ws, float* bufs[6]) {
+constexpr int kBigvganBufs = 12;   // x, xu, xs + 3 x (xj, ua, vb)
+extern "C" int dmel_bigvgan_set_streams(dmel_bigvgan* m, int n_streams) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  DMEL_CHECK_ARG(n_streams == 1 || n_streams == 3, "bigvgan: 1 or 3 streams supported");
+  m->multi = n_streams == 3 && m->cfg.num_kernels > 1 && m->cfg.num_kernels <= 3 && m->ev_fork != nullptr;
+  return DMEL_OK;
+}
+
+static size_t bigvgan_plan(const dmel_bigvgan* m, int B, int64_t T, void* ws, float* bufs[kBigvganBufs]) {
   const dmel_bigvgan_config& c = m->cfg;
   size_t mx = (size_t)c.upsample_initial_channel * T;
   int64_t Tc = T;
@@ -613,7 +648,7 @@ static size_t bigvgan_plan(const dmel_bigvgan* m, int B, int64_t T, void* ws, fl
     mx = std::max(mx, (size_t)(c.upsample_initial_channel >> (i + 1)) * Tc);
   }
   Arena a(ws, (size_t)-1);
-  for (int i = 0; i < 6; ++i) {
+  for (int i = 0; i < kBigvganBufs; ++i) {
     float* p = a.take<float>(mx * B);
     if (bufs) bufs[i] = p;
   }
@@ -630,13 +665,14 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
   DMEL_CHECK_ARG(m && mel && audio && workspace, "bigvgan_forward: NULL argument");
   if (!m->ready) { set_error("bigvgan_forward: handle not finalized"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG(B > 0 && T > 0, "bigvgan_forward: bad shape");
-  float* bufs[6];
+  float* bufs[kBigvganBufs];
   const size_t need = bigvgan_plan(m, B, T, workspace, bufs);
   DMEL_CHECK_ARG(workspace_bytes >= need, "bigvgan_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   const dmel_bigvgan_config& c = m->cfg;
   const int logscale = c.snake_logscale;
-  float *x = bufs[0], *xu = bufs[1], *xj = bufs[2], *ua = bufs[3], *vb = bufs[4], *xs = bufs[5];
+  float *x = bufs[0], *xu = bufs[1], *xs = bufs[2];
+  float* ua = bufs[4];   // block 0's activation scratch doubles as the post-activation buffer
 
   {  // conv_pre (bigvgan.py:369)
     ConvRun r = run_1seg(mel, c.num_mels, T, x, c.upsample_initial_channel, T, B);
@@ -655,22 +691,38 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
     ch = us.Cout;
     Tc = Tn;
     const int64_t bs = (int64_t)ch * Tc;
+    const bool multi = m->multi;
+    if (multi) {  // fork: the side streams start behind the transposed conv
+      DMEL_HIP(hipEventRecord(m->ev_fork, st));
+      for (int k = 0; k < dmel_bigvgan::kSide; ++k) DMEL_HIP(hipStreamWaitEvent(m->side[k], m->ev_fork, 0));
+    }
     for (int j = 0; j < c.num_kernels; ++j) {  // AMPBlock1.forward (bigvgan.py:132-141), summed and averaged (:376-382)
       const AmpBlock& ab = m->blocks[(size_t)i * c.num_kernels + j];
+      hipStream_t sj = (multi && j > 0) ? m->side[j - 1] : st;
+      float *xj = bufs[3 + 3 * j], *uj = bufs[4 + 3 * j], *vj = bufs[5 + 3 * j];
       const float* xin = xu;
       for (int l = 0; l < 3; ++l) {
-        DMEL_TRY(launch_aa_snake(xin, ua, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps, logscale, B, ch, Tc, st));
-        ConvRun r1 = run_1seg(ua, ch, Tc, vb, ch, Tc, B);
-        DMEL_TRY(launch_conv(ab.c1[l], r1, st));
-        DMEL_TRY(launch_aa_snake(vb, ua, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps, logscale, B, ch, Tc, st));
-        ConvRun r2 = run_1seg(ua, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
+        DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps, logscale, B, ch, Tc, sj));
+        ConvRun r1 = run_1seg(uj, ch, Tc, vj, ch, Tc, B);
+        DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
+        DMEL_TRY(launch_aa_snake(vj, uj, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps, logscale, B, ch, Tc, sj));
+        ConvRun r2 = run_1seg(uj, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
         r2.res = xin; r2.res_bs = bs; r2.res_cs = Tc;
         if (l == 2) {
+          // xs = ((out_0 + out_1) + out_2) / 3, in the reference's order: block j's last conv runs behind block j-1's
           r2.accumulate = j > 0;
           if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
+          if (multi && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
         }
-        DMEL_TRY(launch_conv(ab.c2[l], r2, st));
+        DMEL_TRY(launch_conv(ab.c2[l], r2, sj));
+        if (l == 2 && multi && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_chain[j], sj));
         xin = xj;
+      }
+    }
+    if (multi) {  // join: the caller's stream continues behind every side stream
+      for (int k = 0; k < dmel_bigvgan::kSide && k + 1 < c.num_kernels; ++k) {
+        DMEL_HIP(hipEventRecord(m->ev_join[k], m->side[k]));
+        DMEL_HIP(hipStreamWaitEvent(st, m->ev_join[k], 0));
       }
     }
     std::swap(x, xs);

@@ -168,6 +168,10 @@ class BigVGAN(NativeModule):
         _lib.check(_lib.lib().dmel_bigvgan_create(C.byref(handle), C.byref(cfg)), "bigvgan_create")
         return handle.value
 
+    def set_streams(self, n_streams: int) -> None:
+        """1: all kernels on the current stream; 3 (default): the AMP blocks of a stage overlap on side streams."""
+        _lib.check(_lib.lib().dmel_bigvgan_set_streams(self.native(), n_streams), "bigvgan_set_streams")
+
     @torch.no_grad()
     def forward(self, x):
         """mel (B, num_mels, T) -> audio (B, 1, T * prod(upsample_rates))        (bigvgan.py:367-393)"""

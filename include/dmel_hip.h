@@ -139,6 +139,11 @@ void dmel_bigvgan_destroy(dmel_bigvgan* m);
 int dmel_bigvgan_set_tensor(dmel_bigvgan* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
 int dmel_bigvgan_finalize(dmel_bigvgan* m);
 size_t dmel_bigvgan_workspace_bytes(const dmel_bigvgan* m, int B, int64_t T);
+/* Number of streams the AMP blocks of a stage are spread over: 1 = everything on the caller's stream, 3 (default) =
+ * caller's stream + two library-owned side streams forked/joined with events inside every stage (the VALU-bound
+ * activations of one block then overlap the MFMA-bound convolutions of another).  Results are identical.  A handle's
+ * forward is not re-entrant from two host threads at once (it owns the fork/join events). */
+int dmel_bigvgan_set_streams(dmel_bigvgan* m, int n_streams);
 /* mel (B, num_mels, T) -> audio (B, 1, T * prod(upsample_rates)) */
 int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, float* audio, int B, int64_t T,
                          void* workspace, size_t workspace_bytes, void* stream);
