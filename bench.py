@@ -119,6 +119,8 @@ def main() -> None:
     ap.add_argument("--seconds", type=float, default=1.0, help="clip length")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-budget", type=float, default=15.0, help="seconds of CPU work for the baseline (0 = skip)")
+    ap.add_argument("--streams", type=int, default=3, choices=(1, 3),
+                    help="streams BigVGAN's AMP blocks overlap on in the timed region (1 = serialised, for rocprofv3 runs)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -158,6 +160,7 @@ def main() -> None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    codec.vocoder.set_streams(args.streams)
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -182,7 +185,7 @@ def main() -> None:
     sync_all()
     elapsed_serial = time.perf_counter() - t1
     _lib.prof_enable(False)
-    codec.vocoder.set_streams(3)
+    codec.vocoder.set_streams(args.streams)
     assert torch.isfinite(wav).all() and wav.shape == (args.batch, 1, (L // 256 // 4) * 4 * 256)
 
     conv = _lib.prof_read("conv_igemm")
@@ -205,7 +208,8 @@ def main() -> None:
             "config": {"workload": f"{args.workload}: encode+decode, {sr} Hz, {WORKLOADS[args.workload]['n_mels']} mel, "
                                    f"{WORKLOADS[args.workload]['dmel_groups']} FSQ groups {list(WORKLOADS[args.workload]['levels'])}, "
                                    f"WaveNet 20+20 layers, BigVGAN-base, batch {args.batch} x {args.seconds:g} s per GPU",
-                       "parallelism": f"{world} x independent utterance shards, no collective"},
+                       "parallelism": f"{world} x independent utterance shards, no collective",
+                       "vocoder_streams": args.streams},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)",
                          "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,

@@ -170,7 +170,8 @@ class BigVGAN(NativeModule):
 
     def set_streams(self, n_streams: int) -> None:
         """1: all kernels on the current stream; 3 (default): the AMP blocks of a stage overlap on side streams."""
-        _lib.check(_lib.lib().dmel_bigvgan_set_streams(self.native(), n_streams), "bigvgan_set_streams")
+        with torch.cuda.device(self._device()):
+            _lib.check(_lib.lib().dmel_bigvgan_set_streams(self.native(), n_streams), "bigvgan_set_streams")
 
     @torch.no_grad()
     def forward(self, x):
@@ -185,9 +186,9 @@ class BigVGAN(NativeModule):
             up *= u
         y = torch.empty(B, 1, T * up, dtype=torch.float32, device=x.device)
         L = _lib.lib()
-        h = self.native()
-        ws = self._ws.get(L.dmel_bigvgan_workspace_bytes(h, B, T), x.device)
         with torch.cuda.device(x.device):
+            h = self.native()
+            ws = self._ws.get(L.dmel_bigvgan_workspace_bytes(h, B, T), x.device)
             _lib.check(L.dmel_bigvgan_forward(h, x.data_ptr(), y.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
                                               _lib.stream_ptr()), "bigvgan_forward")
         return y

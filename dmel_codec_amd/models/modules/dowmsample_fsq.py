@@ -108,9 +108,9 @@ class DownsampleFiniteScalarQuantize(NativeModule):
         ids = torch.empty(B, self.groups, T4, dtype=torch.int32, device=z.device)
         pre = torch.empty(self.groups, B, T4, len(self.levels), dtype=torch.float32, device=z.device) if return_prequant else None
         L = _lib.lib()
-        h = self.native()
-        ws = self._ws.get(L.dmel_quantizer_workspace_bytes(h, B, T), z.device)
         with torch.cuda.device(z.device):
+            h = self.native()
+            ws = self._ws.get(L.dmel_quantizer_workspace_bytes(h, B, T), z.device)
             _lib.check(L.dmel_quantizer_encode(h, z.data_ptr(), ids.data_ptr(), _lib.ptr(pre), B, T, ws.data_ptr(),
                                                ws.numel(), _lib.stream_ptr()), "quantizer_encode")
         return (ids, pre) if return_prequant else ids
@@ -127,10 +127,10 @@ class DownsampleFiniteScalarQuantize(NativeModule):
         Tf = T4 * math.prod(self.downsample_factor)
         z = torch.empty(B, self.input_dim, Tf, dtype=torch.float32, device=ids.device)
         L = _lib.lib()
-        h = self.native()
-        ws = self._ws.get(L.dmel_quantizer_workspace_bytes(h, B, Tf), ids.device)
         del n_codes
         with torch.cuda.device(ids.device):
+            h = self.native()
+            ws = self._ws.get(L.dmel_quantizer_workspace_bytes(h, B, Tf), ids.device)
             _lib.check(L.dmel_quantizer_decode(h, ids.data_ptr(), z.data_ptr(), B, T4, ws.data_ptr(), ws.numel(),
                                                _lib.stream_ptr()), "quantizer_decode")
         return z

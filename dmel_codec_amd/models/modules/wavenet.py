@@ -136,11 +136,10 @@ class WaveNet(NativeModule):
 
         il, ol = lens(in_lengths), lens(out_lengths)
         L = _lib.lib()
-        h = self.native()
         y = torch.empty(N, self.output_channels, T, dtype=torch.float32, device=dev)
-        nbytes = L.dmel_wavenet_workspace_bytes(h, N, T)
-        ws = self._ws.get(nbytes, dev)
-        with torch.cuda.device(dev):
+        with torch.cuda.device(dev):      # handle creation (weight upload, side streams) must happen on x's device
+            h = self.native()
+            ws = self._ws.get(L.dmel_wavenet_workspace_bytes(h, N, T), dev)
             _lib.check(L.dmel_wavenet_forward(h, x.data_ptr(), _lib.ptr(condition), y.data_ptr(), N, T, _lib.ptr(il),
                                               _lib.ptr(ol), group_repeat, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
                        "wavenet_forward")

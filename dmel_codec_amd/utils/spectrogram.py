@@ -66,16 +66,16 @@ class LinearSpectrogram(nn.Module):
         if y.stride(-1) != 1:
             y = y.contiguous()
         B, Ls = y.shape
-        plan = self._get_plan()
         L = _lib.lib()
-        T = L.dmel_stft_num_frames(plan, Ls)
-        out = torch.empty(B, self.num_mels, T, dtype=torch.float32, device=y.device)
         lens = None
         if lengths is not None:
             lens = lengths.reshape(-1).to(device=y.device, dtype=torch.int64).contiguous()
             if lens.numel() != B:
                 raise ValueError("lengths must have one entry per batch item")
-        with torch.cuda.device(y.device):
+        with torch.cuda.device(y.device):        # the plan's tables live on the device that is current at creation
+            plan = self._get_plan()
+            T = L.dmel_stft_num_frames(plan, Ls)
+            out = torch.empty(B, self.num_mels, T, dtype=torch.float32, device=y.device)
             _lib.check(L.dmel_stft_logmel_f32(plan, y.data_ptr(), y.stride(0), _lib.ptr(lens), out.data_ptr(), B, Ls,
                                               _lib.stream_ptr()), "stft_logmel")
         return out

@@ -280,7 +280,7 @@ def assert_close_to_truth(y, ref32, ref64, what=""):
     float64: the kernel must be within 1e-4 of the truth or within 3x the fp32 oracle's own distance from it."""
     e_gpu, e_ref = rel_err(y, ref64), rel_err(ref32, ref64)
     assert e_gpu < max(TOL, 3.0 * e_ref), f"{what}: gpu-vs-fp64 {e_gpu:.2e}, oracle-fp32-vs-fp64 {e_ref:.2e}"
-    assert rel_err(y, ref32) < 3.0 * TOL, what
+    assert rel_err(y, ref32) < 4.0 * max(TOL, e_ref), what      # two fp32 results can sit on opposite sides of the truth
 
 
 def to64(sd):
@@ -302,6 +302,29 @@ def test_bigvgan_base_config(dev):
     y = m.to(dev)(mel.to(dev))
     assert y.shape == ref.shape == (2, 1, 12 * 256)
     assert_close_to_truth(y, ref, ref64, "bigvgan-base")
+
+
+@pytest.mark.parametrize("name", ["v2_24k_100band_256x", "v2_44k_128band_512x"])
+def test_bigvgan_v2_configs(dev, name):
+    """The 112 M / 122 M parameter v2 vocoders (BASELINE config 4; six stages, 1536 -> 24 channels, no final tanh/bias)
+    on a 3-frame mel: exercises channel counts that are not multiples of 32 and every stage's transposed conv."""
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    from dmel_codec_amd.configs import bigvgan_h
+    h = bigvgan_h(name)
+    torch.manual_seed(21)
+    m = BigVGAN(h)
+    randomise(m, 22, scale=0.7)
+    with torch.no_grad():
+        m.conv_post.weight_g.fill_(0.02)     # keep the random net's output inside the final clamp(-1, 1)
+    mel = torch.randn(1, h.num_mels, 3)
+    sd = cpu_sd(m)
+    ref = ref_cpu.bigvgan_forward(sd, dict(h), mel)
+    ref64 = ref_cpu.bigvgan_forward(to64(sd), dict(h), mel.double())
+    y = m.to(dev)(mel.to(dev))
+    up = math.prod(h.upsample_rates)
+    assert y.shape == ref.shape == (1, 1, 3 * up)
+    assert float(ref.abs().max()) < 0.999 and float(ref.abs().mean()) > 1e-3      # neither saturated nor dead
+    assert_close_to_truth(y, ref, ref64, name)
 
 
 # ------------------------------------------------------------------------------------ whole codec
