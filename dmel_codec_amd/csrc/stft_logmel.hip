@@ -75,13 +75,24 @@ __device__ __forceinline__ int64_t reflect_index(int64_t s, int64_t L) {
   return s;
 }
 
+// LDS operations of one wave execute in order, so the phases of a frame (which only exchange data between the lanes of
+// ONE wave) need a wave-local fence, not a workgroup barrier: the four waves of a workgroup run their frames
+// independently and meet once, before the coalesced tile store.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+constexpr int kMaxMelW = 1536;   // non-zero mel weights (each FFT bin feeds at most two bands: <= 2*513)
+
 __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const float* __restrict__ audio,
                                                           int64_t row_stride, const int64_t* __restrict__ lengths,
                                                           float* __restrict__ out, int64_t L, int64_t T, int hop,
-                                                          int pad, int n_mels) {
-  __shared__ cf bufA[kWaves][kExch];
-  __shared__ cf bufB[kWaves][kExch];
+                                                          int pad, int n_mels, int n_melw) {
+  __shared__ cf buf[kWaves][kExch];            // one exchange buffer per wave, reused by all three passes
   __shared__ float mag[kWaves][kHalf + 8];
+  __shared__ float melw[kMaxMelW];
   __shared__ float tile[kMaxMels][kFramesPerWG + 1];
 
   const int tid = threadIdx.x;
@@ -91,39 +102,51 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
   const int64_t t0 = (int64_t)blockIdx.x * kFramesPerWG;
   const float* x = audio + (int64_t)b * row_stride;
 
+  for (int i = tid; i < n_melw; i += 256) melw[i] = tb.mel_w[i];
+
   // per-lane constants kept in registers across the 8 frames
-  cf wz[8], w1[8], w2[8];
+  cf wz[8], w1[8], w2[8], wr[5];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     wz[j] = tb.winz[64 * j + lane];
     w1[j] = tb.tw1[64 * j + lane];
     w2[j] = tb.tw2[8 * j + (lane & 7)];
   }
+#pragma unroll
+  for (int j = 0; j < 5; ++j) wr[j] = tb.twr[min(lane + 64 * j, 256)];
+  // the (up to two) mel bands of this lane
+  int mst[2], mcnt[2], mptr[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int m = lane + 64 * q;
+    const bool has = m < n_mels;
+    mst[q] = has ? tb.mel_start[m] : 0;
+    mcnt[q] = has ? tb.mel_cnt[m] : 0;
+    mptr[q] = has ? tb.mel_ptr[m] : 0;
+  }
   const int k1 = lane >> 3, l7 = lane & 7;
-  cf* A = bufA[wave];
-  cf* Bx = bufB[wave];
+  cf* A = buf[wave];
   float* mg = mag[wave];
+  __syncthreads();   // melw visible
 
   for (int fi = 0; fi < kFramesPerWave; ++fi) {
     const int f = wave * kFramesPerWave + fi;
     const int64_t t = t0 + f;
-    const bool valid = t < T;
+    if (t >= T) break;                 // wave-uniform: the rest of this wave's frames are past the clip
     cf r[8];
     // ---- load + reflect pad + window; lane = n2, reg j = n1, point n = 64 j + lane
+    const int fstart = (int)t * hop - pad;                       // host checks L < 2^30: 32-bit sample offsets
+    const bool interior = (fstart >= 0) && (fstart + kNfft <= (int)L);
+    const float* xf = x + fstart + 2 * lane;
+    if (interior) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float a0 = 0.f, a1 = 0.f;
-      if (valid) {
-        int64_t s = t * hop + 2 * (64 * j + lane) - pad;
-        int64_t s0 = s, s1 = s + 1;
-        if (s < 0 || s1 >= L) {
-          s0 = reflect_index(s0, L);
-          s1 = reflect_index(s1, L);
-        }
-        a0 = x[s0];
-        a1 = x[s1];
+      for (int j = 0; j < 8; ++j) r[j] = {xf[128 * j] * wz[j].x, xf[128 * j + 1] * wz[j].y};
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t s0 = reflect_index(fstart + 2 * lane + 128 * j, L), s1 = reflect_index(fstart + 2 * lane + 128 * j + 1, L);
+        r[j] = {x[s0] * wz[j].x, x[s1] * wz[j].y};
       }
-      r[j] = {a0 * wz[j].x, a1 * wz[j].y};
     }
     // ---- pass 1: DFT over n1, twiddle W512^(k1 n2)
     dft8(r);
@@ -131,25 +154,27 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
     for (int j = 1; j < 8; ++j) r[j] = cmul(r[j], w1[j]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) A[j * 72 + lane] = r[j];
-    __syncthreads();
+    wave_sync();
     // lane = (k1, m2); reg m1 <- A[k1][8 m1 + m2]
 #pragma unroll
     for (int j = 0; j < 8; ++j) r[j] = A[k1 * 72 + 8 * j + l7];
+    wave_sync();   // all reads done before the buffer is overwritten
     // ---- pass 2: DFT over m1, twiddle W64^(j1 m2)
     dft8(r);
 #pragma unroll
     for (int j = 1; j < 8; ++j) r[j] = cmul(r[j], w2[j]);
     // transpose inside each 8-lane group: writer (k1, m2) reg j1 -> reader (k1, j1) reg m2
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Bx[k1 * 72 + j + 9 * l7] = r[j];
-    __syncthreads();
+    for (int j = 0; j < 8; ++j) A[k1 * 72 + j + 9 * l7] = r[j];
+    wave_sync();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = Bx[k1 * 72 + l7 + 9 * j];
+    for (int j = 0; j < 8; ++j) r[j] = A[k1 * 72 + l7 + 9 * j];
+    wave_sync();
     // ---- pass 3: DFT over m2 -> Z[k1 + 8 j1 + 64 j2]; store in natural order, one pad slot per 8
     dft8(r);
 #pragma unroll
     for (int j = 0; j < 8; ++j) A[k1 + 9 * l7 + 72 * j] = r[j];
-    __syncthreads();
+    wave_sync();
     // ---- real-FFT recombination + magnitude; lane handles k = lane + 64 j and its mirror 512 - k
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
@@ -159,22 +184,26 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
         cf zk = A[k + (k >> 3)], zm = A[km + (km >> 3)];
         cf e = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
         cf o = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
-        cf wo = cmul(tb.twr[k], o);
+        cf wo = cmul(wr[j], o);
         cf xk = cadd(e, wo), xm = csub(e, wo);
-        mg[k] = sqrtf(xk.x * xk.x + xk.y * xk.y + 1e-9f);
-        mg[kHalf - k] = sqrtf(xm.x * xm.x + xm.y * xm.y + 1e-9f);
+        // v_sqrt_f32 (1 ulp; the argument is >= 1e-9, never denormal) instead of the 12-instruction IEEE sequence
+        mg[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y + 1e-9f);
+        mg[kHalf - k] = __builtin_amdgcn_sqrtf(xm.x * xm.x + xm.y * xm.y + 1e-9f);
       }
     }
-    __syncthreads();
-    // ---- mel: one lane per band, ascending-bin fma chain over the band's triangle
-    for (int m = lane; m < n_mels; m += 64) {
-      const int st = tb.mel_start[m], cnt = tb.mel_cnt[m];
-      const float* w = tb.mel_w + tb.mel_ptr[m];
-      float acc = 0.f;
-      for (int i = 0; i < cnt; ++i) acc = fmaf(w[i], mg[st + i], acc);
-      tile[m][f] = logf(fmaxf(acc, 1e-5f));
+    wave_sync();
+    // ---- mel: one lane per band, ascending-bin fma chain over the band's triangle (weights from LDS)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      if (lane + 64 * q < n_mels) {
+        const float* w = melw + mptr[q];
+        const float* g = mg + mst[q];
+        float acc = 0.f;
+        for (int i = 0; i < mcnt[q]; ++i) acc = fmaf(w[i], g[i], acc);
+        tile[lane + 64 * q][f] = logf(fmaxf(acc, 1e-5f));
+      }
     }
-    // (the next frame's writes to mg/A/Bx are each separated from these reads by a barrier above)
+    wave_sync();   // mg and A are rewritten by the next frame
   }
   __syncthreads();
   const int64_t n_valid = lengths ? lengths[b] / hop : T;
@@ -195,6 +224,7 @@ struct dmel_stft_plan {
   double f_min, f_max;
   std::vector<float> basis;  // dense (n_mels, 513), host copy
   DevBuf winz, tw1, tw2, twr, mel_start, mel_cnt, mel_ptr, mel_w;
+  int n_melw = 0;
 };
 
 namespace {
@@ -291,6 +321,12 @@ extern "C" int dmel_stft_plan_create(dmel_stft_plan** out, int sample_rate, int 
     for (int k = 0; k < cnt[m]; ++k) packed.push_back(p->basis[(size_t)m * nb + st[m] + k]);
   }
   if (packed.empty()) packed.push_back(0.f);
+  if ((int)packed.size() > kMaxMelW) {
+    set_error("stft_logmel: %zu non-zero mel weights exceed the LDS table (%d)", packed.size(), kMaxMelW);
+    delete p;
+    return DMEL_EUNSUPPORTED;
+  }
+  p->n_melw = (int)packed.size();
   int rc = DMEL_OK;
   if ((rc = p->winz.upload(winz.data(), winz.size() * sizeof(cf))) || (rc = p->tw1.upload(tw1.data(), tw1.size() * sizeof(cf))) ||
       (rc = p->tw2.upload(tw2.data(), tw2.size() * sizeof(cf))) || (rc = p->twr.upload(twr.data(), twr.size() * sizeof(cf))) ||
@@ -333,6 +369,7 @@ extern "C" int dmel_stft_logmel_f32(const dmel_stft_plan* p, const float* audio,
   DMEL_CHECK_ARG(B > 0 && B <= 65535, "batch %d out of range", B);
   DMEL_CHECK_ARG(L > p->pad, "clip length %lld must exceed the reflect pad %d", (long long)L, p->pad);
   DMEL_CHECK_ARG(row_stride >= L, "row stride smaller than L");
+  DMEL_CHECK_ARG(L < ((int64_t)1 << 30), "clip longer than 2^30 samples");
   const int64_t T = dmel_stft_num_frames(p, L);
   DMEL_CHECK_ARG(T > 0, "clip too short for one frame");
   StftTables tb{p->winz.as<cf>(), p->tw1.as<cf>(), p->tw2.as<cf>(), p->twr.as<cf>(), p->mel_start.as<int>(),
@@ -342,7 +379,7 @@ extern "C" int dmel_stft_logmel_f32(const dmel_stft_plan* p, const float* audio,
   {
     ProfScope ps("stft_logmel", s, 0.0, (double)B * (4.0 * (double)L + 4.0 * p->n_mels * (double)T));
     hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(256), 0, s, tb, audio, row_stride, lengths, out, L, T, p->hop,
-                       p->pad, p->n_mels);
+                       p->pad, p->n_mels, p->n_melw);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
