@@ -143,3 +143,53 @@ class VQGAN(nn.Module):
                 raise ValueError("Vocoder is not loaded")
             return self.vocoder(gen_mel), gen_mel
         return gen_mel
+
+    # ------------------------------------------------------------------------------ streaming decode (extension)
+    #: mel frames of context the decode path needs on each side of a chunk for its interior to be exact:
+    #: conditional WaveNet 20 layers x dilations (1,2,4,8) = 75, BigVGAN-base ~19 (conv_pre 3 + AMP/snake halos of the
+    #: four stages), quantiser ConvNeXt stacks ~3.  Chunks carry a 32-token (128-frame) halo.
+    STREAM_HALO_TOKENS = 32
+
+    @torch.no_grad()
+    def decode_stream(self, indices, feature_lengths, chunk_tokens: int = 64, halo_tokens: Optional[int] = None,
+                      noise: Optional[torch.Tensor] = None, return_audios: bool = True):
+        """Generator over time chunks of decode(): yields (audio (B,1,n*256*4) | None, gen_mel (B,n_mels,n*4)) for
+        successive windows of `chunk_tokens` token frames, each decoded with `halo_tokens` of context on both sides
+        and cropped.  Every layer of the decode path is a finite-support convolution, so with the halo at least the
+        receptive field the concatenation is BIT-identical to decode() on the whole sequence (tests): bounded memory
+        for long audio, and audio can be emitted while an LM is still producing tokens (the reference decodes once
+        at the end, lm_lit_modules.py:467-471).  `noise`: (B, C, 4*T4) for reproducible runs, else drawn per chunk."""
+        if self.decoder is None:
+            raise ValueError("Decoder is not loaded")
+        halo = self.STREAM_HALO_TOKENS if halo_tokens is None else int(halo_tokens)
+        feature_lengths = self._lengths(feature_lengths)
+        B, G, T4 = indices.shape
+        factor = math.prod(self.quantizer.downsample_factor)
+        hop = self.encode_mel_transform.hop_length
+        up = 1
+        if return_audios:
+            if self.vocoder is None:
+                raise ValueError("Vocoder is not loaded")
+            for u in self.vocoder.h.upsample_rates:
+                up *= u
+        for start in range(0, T4, chunk_tokens):
+            stop = min(start + chunk_tokens, T4)
+            lo, hi = max(0, start - halo), min(T4, stop + halo)
+            ids = indices[:, :, lo:hi].contiguous()
+            lens = (feature_lengths.to(indices.device) - lo).clamp(min=0, max=hi - lo)
+            nz = noise[:, :, lo * factor:hi * factor].contiguous() if noise is not None else None
+            out = self.decode(ids, lens, return_audios=return_audios, noise=nz)
+            audio, mel = out if return_audios else (None, out)
+            a, b = (start - lo) * factor, (stop - lo) * factor
+            yield (audio[:, :, a * up:b * up] if audio is not None else None), mel[:, :, a:b]
+        del hop
+
+    @torch.no_grad()
+    def decode_chunked(self, indices, feature_lengths, chunk_tokens: int = 64, halo_tokens: Optional[int] = None,
+                       noise: Optional[torch.Tensor] = None, return_audios: bool = True):
+        """decode() evaluated chunk by chunk (decode_stream) and concatenated: same result, bounded workspace."""
+        parts = list(self.decode_stream(indices, feature_lengths, chunk_tokens, halo_tokens, noise, return_audios))
+        mel = torch.cat([p[1] for p in parts], dim=-1)
+        if return_audios:
+            return torch.cat([p[0] for p in parts], dim=-1), mel
+        return mel

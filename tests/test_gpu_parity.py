@@ -416,3 +416,27 @@ def test_codec_round_trip_properties(dev):
     short[0] = 5
     mel2 = codec.decode(ids1, short, noise=noise)
     assert torch.all(mel2[0, :, 20:] == 0) and torch.equal(mel2[1:], mel[1:])
+
+
+def test_streaming_decode_is_bit_identical(dev):
+    """decode_stream / decode_chunked (halo'd time chunks) against decode() on the whole sequence: every layer has finite
+    support, so with a halo >= the receptive field the concatenation must be bit-identical (12.8 s, ragged batch)."""
+    codec = make_codec(700, n_mels=80, dmel_groups=8, encoder_layers=2).to(dev)
+    gen = torch.Generator().manual_seed(9)
+    B, T4 = 2, 300
+    ids = torch.randint(0, 175, (B, 8, T4), generator=gen, dtype=torch.int32).to(dev)
+    flen = torch.tensor([T4, 211], device=dev)
+    noise = torch.randn(B, 560, T4 * 4, generator=gen).to(dev)
+    audio, mel = codec.decode(ids, flen, return_audios=True, noise=noise)
+    audio_c, mel_c = codec.decode_chunked(ids, flen, chunk_tokens=64, noise=noise)
+    assert audio_c.shape == audio.shape == (B, 1, T4 * 4 * 256) and mel_c.shape == mel.shape
+    assert torch.equal(mel_c, mel)
+    assert torch.equal(audio_c, audio)
+    n = 0
+    for a, m in codec.decode_stream(ids, flen, chunk_tokens=100, noise=noise):
+        assert torch.equal(a, audio[:, :, n * 1024:n * 1024 + a.shape[-1]])
+        n += m.shape[-1] // 4
+    assert n == T4
+    # too small a halo must NOT be exact (the test would otherwise be vacuous)
+    audio_bad, _ = codec.decode_chunked(ids, flen, chunk_tokens=64, halo_tokens=2, noise=noise)
+    assert not torch.equal(audio_bad, audio)
