@@ -35,6 +35,7 @@ struct SegArgs {
 struct KArgs {
   SegArgs seg[2];
   int nseg, steps, mtiles;
+  int gx, gy, gz, xcd_chunk;   // logical grid (column tiles, m blocks, batch); xcd_chunk > 0: 1-D XCD-chunked launch
   const float* w;
   const float* bias;
   int64_t Tcols;
@@ -136,6 +137,27 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
   }
 }
 
+// Workgroup -> (column tile, m block, batch item).  Plain 3-D launch, or (xcd_chunk > 0) a 1-D launch in which the
+// hardware's round-robin of consecutive workgroup ids over the 8 XCDs is undone: the m-block-major work list is cut
+// into 8 contiguous chunks and XCD label j = id % 8 walks chunk j, so one XCD's L2 holds a contiguous 1/8 of the
+// weight rows (and re-reads each x tile for its few m blocks) instead of every XCD streaming all weights through the
+// Infinity Cache.  Purely a locality choice: any placement gives the same result.
+__device__ __forceinline__ bool conv_block_coords(const KArgs& a, int& tile_n, int& mblk, int& b) {
+  if (a.xcd_chunk <= 0) {
+    tile_n = blockIdx.x; mblk = blockIdx.y; b = blockIdx.z;
+    return true;
+  }
+  const int id = blockIdx.x;
+  const int w = (id & 7) * a.xcd_chunk + (id >> 3);
+  const int per_m = a.gx * a.gz;
+  if ((id >> 3) >= a.xcd_chunk || w >= per_m * a.gy) return false;
+  mblk = w / per_m;
+  const int rest = w - mblk * per_m;
+  b = rest / a.gx;
+  tile_n = rest - b * a.gx;
+  return true;
+}
+
 // HALO = 64: any (taps-1)*dilation <= 64.  HALO = 0: every segment is 1-tap (pointwise convs, Linear layers): a
 // third less staging work and LDS, which buys those launch-bound kernels a wave of occupancy.
 template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO>
@@ -150,8 +172,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArg
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
   const int h = lane >> 5, l31 = lane & 31;
-  const int q0 = blockIdx.x * BN;
-  const int mblk = blockIdx.y, b = blockIdx.z;
+  int tile_n, mblk, b;
+  if (!conv_block_coords(a, tile_n, mblk, b)) return;   // whole workgroup exits together (padding of the 1-D grid)
+  const int q0 = tile_n * BN;
   const int lb = b / a.len_div;
 
   floatx16 acc[MT][NT];
@@ -286,8 +309,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_direct_kernel(KAr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
   const int h = lane >> 5, l31 = lane & 31;
-  const int q0 = blockIdx.x * BN;
-  const int mblk = blockIdx.y, b = blockIdx.z;
+  int tile_n, mblk, b;
+  if (!conv_block_coords(a, tile_n, mblk, b)) return;   // whole workgroup exits together (padding of the 1-D grid)
+  const int q0 = tile_n * BN;
   const int lb = b / a.len_div;
 
   floatx16 acc[MT][NT];
@@ -381,14 +405,35 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_direct_kernel(KAr
   conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), qcol, b, lb, h);
 }
 
-template <int WM, int WN, int MT, int NT, int MODE> static int launch_d(const KArgs& ka, int B, int mblocks, hipStream_t st) {
-  constexpr int BN = WN * NT * 32;
-  dim3 grid((unsigned)((ka.Tcols + BN - 1) / BN), (unsigned)mblocks, (unsigned)B);
-  if (grid.y > 65535 || grid.z > 65535) {
-    set_error("conv_igemm: grid too large (mblocks %u, batch %u)", grid.y, grid.z);
+// Fills the logical grid into the kernel arguments and returns the launch grid.  The XCD-chunked 1-D form is used
+// when the weights of the launch do not fit one XCD's 4 MiB L2 next to the activations (large-M GEMMs: the WaveNet
+// decoder); small weight sets are L2-resident on every XCD anyway and keep the plain 3-D grid.
+static int conv_grid(KArgs& k, int gx, int gy, int gz, dim3& grid) {
+  static int mode = [] { const char* e = getenv("DMEL_CONV_XCD"); return e ? atoi(e) : -1; }();   // -1 auto, 0 off, 1 on
+  k.gx = gx; k.gy = gy; k.gz = gz;
+  const double weight_bytes = (double)k.mtiles * 32.0 * k.steps * kCK * 4.0;
+  const bool want = mode == 1 || (mode == -1 && weight_bytes > 2.5e6 && gy >= 8);
+  const int64_t total = (int64_t)gx * gy * gz;
+  if (want && total < ((int64_t)1 << 30)) {
+    k.xcd_chunk = (int)((total + 7) / 8);
+    grid = dim3((unsigned)(k.xcd_chunk * 8));
+    return DMEL_OK;
+  }
+  k.xcd_chunk = 0;
+  if (gy > 65535 || gz > 65535) {
+    set_error("conv_igemm: grid too large (mblocks %d, batch %d)", gy, gz);
     return DMEL_EINVAL;
   }
-  hipLaunchKernelGGL((conv_direct_kernel<WM, WN, MT, NT, MODE>), grid, dim3(64 * WM * WN), 0, st, ka);
+  grid = dim3((unsigned)gx, (unsigned)gy, (unsigned)gz);
+  return DMEL_OK;
+}
+
+template <int WM, int WN, int MT, int NT, int MODE> static int launch_d(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+  constexpr int BN = WN * NT * 32;
+  KArgs k2 = ka;
+  dim3 grid;
+  DMEL_TRY(conv_grid(k2, (int)((ka.Tcols + BN - 1) / BN), mblocks, B, grid));
+  hipLaunchKernelGGL((conv_direct_kernel<WM, WN, MT, NT, MODE>), grid, dim3(64 * WM * WN), 0, st, k2);
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
 }
@@ -397,12 +442,10 @@ template <int WM, int WN, int MT, int NT, int MODE, int HALO>
 static int launch_h(const KArgs& ka, int B, int mblocks, hipStream_t st) {
   constexpr int BN = WN * NT * 32;
   const size_t lds = (size_t)(2 * kCK * (BN + HALO)) * sizeof(float);
-  dim3 grid((unsigned)((ka.Tcols + BN - 1) / BN), (unsigned)mblocks, (unsigned)B);
-  if (grid.y > 65535 || grid.z > 65535) {
-    set_error("conv_igemm: grid too large (mblocks %u, batch %u)", grid.y, grid.z);
-    return DMEL_EINVAL;
-  }
-  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, MODE, HALO>), grid, dim3(64 * WM * WN), lds, st, ka);
+  KArgs k2 = ka;
+  dim3 grid;
+  DMEL_TRY(conv_grid(k2, (int)((ka.Tcols + BN - 1) / BN), mblocks, B, grid));
+  hipLaunchKernelGGL((conv_igemm_kernel<WM, WN, MT, NT, MODE, HALO>), grid, dim3(64 * WM * WN), lds, st, k2);
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
 }
