@@ -132,15 +132,10 @@ def test_fsq_fixture_and_invariants(golden):
 
 
 def test_schedule_fixture(golden):
-    """utils/schedule.py:4-25 restated inline (host logic used by train entry point later)."""
-    import math
+    """utils/schedule.py:4-25: the product's schedule function against values produced by the reference's."""
+    from dmel_codec_amd.utils.schedule import get_cosine_schedule_with_warmup_lr_lambda as lr_lambda
     g = golden("schedule")
-
-    def lr_lambda(step, warm=100, total=1000000, final=0.05, cycles=0.5):
-        if step < warm:
-            return step / max(1, warm)
-        prog = (step - warm) / max(1, total - warm)
-        return max(final, 0.5 * (1.0 + math.cos(math.pi * cycles * 2.0 * prog)))
-
-    vals = torch.tensor([lr_lambda(int(s)) for s in g.ins["steps"]])
+    vals = torch.tensor([lr_lambda(int(s), num_warmup_steps=100, num_training_steps=1000000, final_lr_ratio=0.05)
+                         for s in g.ins["steps"]])
     assert torch.allclose(vals, g.outs["lr"], atol=1e-7)
+    assert lr_lambda(10, num_warmup_steps=0.1, num_training_steps=1000) == 0.1      # fractional warm-up
