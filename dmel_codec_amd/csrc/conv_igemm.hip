@@ -158,8 +158,9 @@ __device__ __forceinline__ bool conv_block_coords(const KArgs& a, int& tile_n, i
   return true;
 }
 
-// HALO = 64: any (taps-1)*dilation <= 64.  HALO = 0: every segment is 1-tap (pointwise convs, Linear layers): a
-// third less staging work and LDS, which buys those launch-bound kernels a wave of occupancy.
+// HALO = 64: any (taps-1)*dilation <= 64.  HALO = 16: receptive fields up to 17 samples (all dilation-1 convs).
+// HALO = 0: every segment is 1-tap (pointwise convs, Linear layers).  Smaller halos mean less staging work and LDS
+// per chunk, which buys the short kernels a wave of occupancy.
 template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_igemm_kernel(KArgs a) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NW = WAVES_M * WAVES_N;
@@ -451,9 +452,12 @@ static int launch_h(const KArgs& ka, int B, int mblocks, hipStream_t st) {
 }
 
 template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KArgs& ka, int B, int mblocks, hipStream_t st) {
-  bool pointwise = true;
-  for (int s = 0; s < ka.nseg; ++s) pointwise = pointwise && ka.seg[s].taps == 1;
-  return pointwise ? launch_h<WM, WN, MT, NT, MODE, 0>(ka, B, mblocks, st) : launch_h<WM, WN, MT, NT, MODE, 64>(ka, B, mblocks, st);
+  int halo = 0;
+  for (int s = 0; s < ka.nseg; ++s) halo = std::max(halo, (ka.seg[s].taps - 1) * ka.seg[s].dil);
+  if (halo == 0) return launch_h<WM, WN, MT, NT, MODE, 0>(ka, B, mblocks, st);
+  // dilation-1 convs (every second conv of an AMP block, k2 transposed-conv phases): a 16-column halo is enough
+  if (halo <= 16) return launch_h<WM, WN, MT, NT, MODE, 16>(ka, B, mblocks, st);
+  return launch_h<WM, WN, MT, NT, MODE, 64>(ka, B, mblocks, st);
 }
 
 // ---- tile selection -------------------------------------------------------------------------------------------
