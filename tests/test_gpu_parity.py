@@ -440,3 +440,40 @@ def test_streaming_decode_is_bit_identical(dev):
     # too small a halo must NOT be exact (the test would otherwise be vacuous)
     audio_bad, _ = codec.decode_chunked(ids, flen, chunk_tokens=64, halo_tokens=2, noise=noise)
     assert not torch.equal(audio_bad, audio)
+
+
+def test_ragged_batch_with_empty_item(dev):
+    """A batch whose second item is shorter than one hop (0 valid frames -> 0 valid tokens): ids and lengths must still
+    match the oracle for every item, and decode must emit the all-masked result for the empty one."""
+    from dmel_codec_amd.configs import oracle_cfg
+    codec = make_codec(900, n_mels=80, dmel_groups=8, encoder_layers=3, decoder_layers=2, vocoder=None)
+    cfg = oracle_cfg(codec)
+    sd, _ = split_sd(codec)
+    gen = torch.Generator().manual_seed(77)
+    L = 6000
+    audio = torch.randn(3, 1, L, generator=gen) * 0.2
+    lens = torch.tensor([L, 100, 3333])
+    ids_ref, lens_ref, pre_ref = ref_cpu.vqgan_encode(sd, cfg, audio, lens, return_prequant=True)
+    codec = codec.to(dev)
+    ids, ilens = codec.encode(audio.to(dev), lens.to(dev))
+    assert ilens.tolist() == lens_ref.tolist() == [5, 0, 3]
+    n_diff, n_bad, n_tie = near_tie_report(ids, ids_ref, pre_ref)
+    assert n_bad == 0
+    noise = torch.randn(3, 560, ids.shape[2] * 4, generator=gen)
+    mel_ref = ref_cpu.vqgan_decode(sd, cfg, ids_ref, lens_ref, noise)
+    mel = codec.decode(ids_ref.to(dev), lens_ref.to(dev), noise=noise.to(dev))
+    assert rel_err(mel, mel_ref) < TOL
+    assert torch.all(mel[1] == 0)
+
+
+def test_errors_on_bad_shapes(dev):
+    codec = make_codec(910, n_mels=80, dmel_groups=8, encoder_layers=1, decoder_layers=1, vocoder=None).to(dev)
+    with pytest.raises((RuntimeError, ValueError)):
+        codec.encode(torch.zeros(2, 1, 200, device=dev), torch.tensor([200, 200], device=dev))      # shorter than the reflect pad
+    with pytest.raises(ValueError):
+        codec.decode(torch.zeros(1, 7, 4, dtype=torch.int32, device=dev), torch.tensor([4], device=dev))   # 7 groups != 8
+    with pytest.raises(ValueError):
+        codec.decode(torch.zeros(1, 8, 4, dtype=torch.int32, device=dev), torch.tensor([4], device=dev),
+                     noise=torch.zeros(1, 560, 15, device=dev))
+    with pytest.raises(ValueError, match="Vocoder"):
+        codec.decode(torch.zeros(1, 8, 4, dtype=torch.int32, device=dev), torch.tensor([4], device=dev), return_audios=True)
