@@ -461,7 +461,10 @@ struct dmel_bigvgan {
   dmel_bigvgan_config cfg;
   TensorStore ts;
   bool ready = false;
-  PackedConv conv_pre, conv_post;
+  PackedConv conv_pre;
+  DevBuf post_w;            // conv_post weight (1, C, 7) on the device: a single output row runs as a reduction kernel
+  float post_bias = 0.f;
+  int post_c = 0;
   std::vector<UpStage> ups;
   std::vector<AmpBlock> blocks;
   SnakeP act_post;
@@ -625,7 +628,18 @@ extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
     }
   }
   DMEL_TRY(load_snake(m->act_post, m->ts, "activation_post.", ch, snake));
-  DMEL_TRY(pack_same_conv(m->conv_post, m->ts, "conv_post.", 1, ch, 7, 1, c.use_bias_at_final != 0));
+  {
+    std::vector<float> pw;
+    if (!m->ts.conv_weight("conv_post.", {1, ch, 7}, pw)) return DMEL_EMISSING;
+    m->post_bias = 0.f;
+    if (c.use_bias_at_final) {
+      const HostTensor* pb = m->ts.need("conv_post.bias", {1});
+      if (!pb) return DMEL_EMISSING;
+      m->post_bias = pb->v[0];
+    }
+    DMEL_TRY(upload_vec(m->post_w, pw));
+    m->post_c = ch;
+  }
   m->ts.t.clear();
   m->ready = true;
   return DMEL_OK;
@@ -729,7 +743,6 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
   }
   // activation_post, conv_post, tanh | clamp (bigvgan.py:385-391)
   DMEL_TRY(launch_aa_snake(x, ua, m->act_post.alpha.as<float>(), m->act_post.beta.as<float>(), m->taps, logscale, B, ch, Tc, st));
-  ConvRun r = run_1seg(ua, ch, Tc, audio, 1, Tc, B);
-  r.act = c.use_tanh_at_final ? ACT_TANH : ACT_CLAMP1;
-  return launch_conv(m->conv_post, r, st);
+  return launch_conv_post(ua, audio, m->post_w.as<float>(), m->post_bias, c.use_tanh_at_final ? ACT_TANH : ACT_CLAMP1, B, ch, 7,
+                          Tc, st);
 }

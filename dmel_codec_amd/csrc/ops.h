@@ -18,6 +18,9 @@ int launch_fsq_decode(const int32_t* ids, const float* w_out, const float* b_out
                       int G, int C, int64_t T4, hipStream_t s);
 int launch_dwconv_ln(const float* x, float* y, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                      int N, int C, int64_t T, hipStream_t s);
+// act: 2 = tanh, 3 = clamp(-1, 1), else none (values of enum Act)
+int launch_conv_post(const float* x, float* y, const float* w_dev, float bias, int act, int B, int C, int K, int64_t T,
+                     hipStream_t s);
 int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, int N, int C, int64_t T, hipStream_t s);
 int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host, int logscale,
                     int B, int C, int64_t T, hipStream_t s);

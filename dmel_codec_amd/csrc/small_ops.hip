@@ -209,6 +209,55 @@ int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, in
   return DMEL_OK;
 }
 
+// ---- conv_post: C -> 1 channel, k taps, zero "same" padding, then tanh | clamp   (bigvgan.py:386-391) -----------
+// One output row: a 32-row MFMA tile would be 97 % zeros, so this is a plain reduction over (channel, tap) -- HBM
+// bound (C*T*4 bytes read per item, each input row read once per workgroup through L1).
+constexpr int kPostTile = 1024;
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ w, float bias, int C, int K, int T,
+                                                        int act) {
+  extern __shared__ float wsm[];   // [C][K]
+  for (int i = threadIdx.x; i < C * K; i += 256) wsm[i] = w[i];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * kPostTile;
+  const float* xb = x + (int64_t)b * C * T;
+  const int pad = (K - 1) / 2;
+  float acc[4];
+  int tt[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { acc[e] = bias; tt[e] = t0 + threadIdx.x + 256 * e; }
+  for (int c = 0; c < C; ++c) {
+    const float* xr = xb + (int64_t)c * T;
+    for (int k = 0; k < K; ++k) {
+      const float wv = wsm[c * K + k];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = tt[e] + k - pad;
+        const float v = (s >= 0 && s < T) ? xr[s] : 0.f;
+        acc[e] = fmaf(wv, v, acc[e]);
+      }
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (tt[e] < T) y[(int64_t)b * T + tt[e]] = act == 2 ? tanhf(acc[e]) : (act == 3 ? fminf(fmaxf(acc[e], -1.f), 1.f) : acc[e]);
+}
+
+int launch_conv_post(const float* x, float* y, const float* w_dev, float bias, int act, int B, int C, int K, int64_t T,
+                     hipStream_t s) {
+  DMEL_CHECK_ARG(B > 0 && B <= 65535 && C > 0 && K > 0 && (K % 2) == 1 && T > 0 && T < ((int64_t)1 << 30), "conv_post: bad shape");
+  const size_t lds = (size_t)C * K * sizeof(float);
+  DMEL_CHECK_ARG(lds <= 48 * 1024, "conv_post: weight table too large");
+  dim3 grid((unsigned)((T + kPostTile - 1) / kPostTile), (unsigned)B);
+  {
+    ProfScope ps("small", s, 0.0, 4.0 * B * (double)T * (C + 1));
+    hipLaunchKernelGGL(conv_post_kernel, grid, dim3(256), lds, s, x, y, w_dev, bias, C, K, (int)T, act);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
 // ---- z = z * mask + (w * value + bias)      codec_lit_modules.py:520-526 --------------------------
 __global__ __launch_bounds__(256) void mask_add_quality_kernel(float* __restrict__ z, const int64_t* __restrict__ len,
                                                                const float* __restrict__ w, const float* __restrict__ bias,
