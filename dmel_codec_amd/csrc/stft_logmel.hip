@@ -19,12 +19,9 @@
 
 namespace dmel {
 
-constexpr int kNfft = 1024;
-constexpr int kHalf = 512;
 constexpr int kFramesPerWG = 32;
 constexpr int kWaves = 4;
 constexpr int kFramesPerWave = kFramesPerWG / kWaves;
-constexpr int kExch = 8 * 72;  // padded exchange buffer, float2 elements
 constexpr int kMaxMels = 128;
 
 struct cf {
@@ -58,11 +55,39 @@ __device__ __forceinline__ void dft8(cf (&a)[8]) {
   dft4(b4, b5, b6, b7, a[1], a[3], a[5], a[7]);
 }
 
+// 16-point forward DFT (decimation in time over two 8-point DFTs), natural order in and out.
+__device__ __forceinline__ void dft16(cf (&a)[16]) {
+  cf e[8], o[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { e[i] = a[2 * i]; o[i] = a[2 * i + 1]; }
+  dft8(e);
+  dft8(o);
+  const cf w[8] = {{1.f, 0.f},
+                   {0.92387953251128675613f, -0.38268343236508977173f},
+                   {0.70710678118654752440f, -0.70710678118654752440f},
+                   {0.38268343236508977173f, -0.92387953251128675613f},
+                   {0.f, -1.f},
+                   {-0.38268343236508977173f, -0.92387953251128675613f},
+                   {-0.70710678118654752440f, -0.70710678118654752440f},
+                   {-0.92387953251128675613f, -0.38268343236508977173f}};
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const cf t = k == 0 ? o[0] : cmul(w[k], o[k]);
+    a[k] = cadd(e[k], t);
+    a[k + 8] = csub(e[k], t);
+  }
+}
+
+template <int P> __device__ __forceinline__ void dft_p(cf (&a)[P]);
+template <> __device__ __forceinline__ void dft_p<4>(cf (&a)[4]) { dft4(a[0], a[1], a[2], a[3], a[0], a[1], a[2], a[3]); }
+template <> __device__ __forceinline__ void dft_p<8>(cf (&a)[8]) { dft8(a); }
+template <> __device__ __forceinline__ void dft_p<16>(cf (&a)[16]) { dft16(a); }
+
 struct StftTables {
-  const cf* winz;       // [512]   (w[2n], w[2n+1])
-  const cf* tw1;        // [8][64] W512^(k1*lane)
+  const cf* winz;       // [H]     (w[2n], w[2n+1]),  H = n_fft / 2
+  const cf* tw1;        // [P][64] W_H^(k1*lane),     P = H / 64
   const cf* tw2;        // [8][8]  W64^(j1*m2)
-  const cf* twr;        // [257]   W1024^k
+  const cf* twr;        // [H/2+1] W_N^k
   const int* mel_start; // [n_mels] first FFT bin of the band
   const int* mel_cnt;   // [n_mels] number of bins
   const int* mel_ptr;   // [n_mels] offset into mel_w
@@ -84,16 +109,23 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int kMaxMelW = 1536;   // non-zero mel weights (each FFT bin feeds at most two bands: <= 2*513)
+constexpr int kMaxMelW = 2304;   // non-zero mel weights (each FFT bin feeds at most two bands: <= 2*1025)
 
+// n_fft = 128 P (P = 4, 8, 16).  The N/2 = 64 P complex points of a frame are n = 64 n1 + n2 (n1 < P, n2 = lane):
+// pass 1 is a P-point DFT per lane (+ twiddle W_{N/2}^{k1 n2}); every k1 row then needs a 64-point DFT over n2, done as
+// 8 x 8 with two LDS transposes (passes 2 and 3: P*8 independent 8-point DFTs each, i.e. P/8 per lane; for P = 4 half
+// the lanes idle in those passes).  Output index k = k1 + P (j1 + 8 j2).
+template <int P>
 __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const float* __restrict__ audio,
                                                           int64_t row_stride, const int64_t* __restrict__ lengths,
                                                           float* __restrict__ out, int64_t L, int64_t T, int hop,
                                                           int pad, int n_mels, int n_melw) {
-  __shared__ cf buf[kWaves][kExch];            // one exchange buffer per wave, reused by all three passes
-  __shared__ float mag[kWaves][kHalf + 8];
-  __shared__ float melw[kMaxMelW];
-  __shared__ float tile[kMaxMels][kFramesPerWG + 1];
+  constexpr int H = 64 * P, N = 128 * P, U = (P + 7) / 8, EX = P * 72, NR = P / 2 + 1;
+  extern __shared__ __attribute__((aligned(16))) float smem_stft[];
+  cf* buf_all = reinterpret_cast<cf*>(smem_stft);                 // [kWaves][EX]   exchange buffer, reused by every pass
+  float* mag_all = smem_stft + 2 * kWaves * EX;                   // [kWaves][H+8]
+  float* melw = mag_all + kWaves * (H + 8);                       // [kMaxMelW]
+  float (*tile)[kFramesPerWG + 1] = reinterpret_cast<float (*)[kFramesPerWG + 1]>(melw + kMaxMelW);   // [kMaxMels][33]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -104,16 +136,20 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
 
   for (int i = tid; i < n_melw; i += 256) melw[i] = tb.mel_w[i];
 
-  // per-lane constants kept in registers across the 8 frames
-  cf wz[8], w1[8], w2[8], wr[5];
+  // per-lane constants kept in registers across the wave's frames (window and pass-1 twiddles only while they fit)
+  constexpr bool kRegTables = P <= 8;
+  cf wz[kRegTables ? P : 1], w1[kRegTables ? P : 1], w2[8], wr[NR];
+  if constexpr (kRegTables) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    wz[j] = tb.winz[64 * j + lane];
-    w1[j] = tb.tw1[64 * j + lane];
-    w2[j] = tb.tw2[8 * j + (lane & 7)];
+    for (int j = 0; j < P; ++j) {
+      wz[j] = tb.winz[64 * j + lane];
+      w1[j] = tb.tw1[64 * j + lane];
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 5; ++j) wr[j] = tb.twr[min(lane + 64 * j, 256)];
+  for (int j = 0; j < 8; ++j) w2[j] = tb.tw2[8 * j + (lane & 7)];
+#pragma unroll
+  for (int j = 0; j < NR; ++j) wr[j] = tb.twr[min(lane + 64 * j, H / 2)];
   // the (up to two) mel bands of this lane
   int mst[2], mcnt[2], mptr[2];
 #pragma unroll
@@ -124,63 +160,84 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
     mcnt[q] = has ? tb.mel_cnt[m] : 0;
     mptr[q] = has ? tb.mel_ptr[m] : 0;
   }
-  const int k1 = lane >> 3, l7 = lane & 7;
-  cf* A = buf[wave];
-  float* mg = mag[wave];
+  const int k1l = lane >> 3, l7 = lane & 7;
+  cf* A = buf_all + wave * EX;
+  float* mg = mag_all + wave * (H + 8);
   __syncthreads();   // melw visible
 
   for (int fi = 0; fi < kFramesPerWave; ++fi) {
     const int f = wave * kFramesPerWave + fi;
     const int64_t t = t0 + f;
     if (t >= T) break;                 // wave-uniform: the rest of this wave's frames are past the clip
-    cf r[8];
+    cf r[P];
     // ---- load + reflect pad + window; lane = n2, reg j = n1, point n = 64 j + lane
     const int fstart = (int)t * hop - pad;                       // host checks L < 2^30: 32-bit sample offsets
-    const bool interior = (fstart >= 0) && (fstart + kNfft <= (int)L);
+    const bool interior = (fstart >= 0) && (fstart + N <= (int)L);
     const float* xf = x + fstart + 2 * lane;
-    if (interior) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r[j] = {xf[128 * j] * wz[j].x, xf[128 * j + 1] * wz[j].y};
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < P; ++j) {
+      const cf w = kRegTables ? wz[kRegTables ? j : 0] : tb.winz[64 * j + lane];
+      if (interior) {
+        r[j] = {xf[128 * j] * w.x, xf[128 * j + 1] * w.y};
+      } else {
         const int64_t s0 = reflect_index(fstart + 2 * lane + 128 * j, L), s1 = reflect_index(fstart + 2 * lane + 128 * j + 1, L);
-        r[j] = {x[s0] * wz[j].x, x[s1] * wz[j].y};
+        r[j] = {x[s0] * w.x, x[s1] * w.y};
       }
     }
-    // ---- pass 1: DFT over n1, twiddle W512^(k1 n2)
-    dft8(r);
+    // ---- pass 1: DFT over n1, twiddle W_H^(k1 n2)
+    dft_p<P>(r);
 #pragma unroll
-    for (int j = 1; j < 8; ++j) r[j] = cmul(r[j], w1[j]);
+    for (int j = 1; j < P; ++j) r[j] = cmul(r[j], kRegTables ? w1[kRegTables ? j : 0] : tb.tw1[64 * j + lane]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) A[j * 72 + lane] = r[j];
+    for (int j = 0; j < P; ++j) A[j * 72 + lane] = r[j];
     wave_sync();
-    // lane = (k1, m2); reg m1 <- A[k1][8 m1 + m2]
+    // ---- pass 2: lane = (k1, m2), k1 = lane/8 + 8u; reg m1 <- A[k1][8 m1 + m2]; DFT over m1; twiddle W64^(j1 m2)
+    cf rr[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = A[k1 * 72 + 8 * j + l7];
+    for (int u = 0; u < U; ++u) {
+      const int k1 = min(k1l + 8 * u, P - 1);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) rr[u][j] = A[k1 * 72 + 8 * j + l7];
+    }
     wave_sync();   // all reads done before the buffer is overwritten
-    // ---- pass 2: DFT over m1, twiddle W64^(j1 m2)
-    dft8(r);
 #pragma unroll
-    for (int j = 1; j < 8; ++j) r[j] = cmul(r[j], w2[j]);
-    // transpose inside each 8-lane group: writer (k1, m2) reg j1 -> reader (k1, j1) reg m2
+    for (int u = 0; u < U; ++u) {
+      dft8(rr[u]);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) A[k1 * 72 + j + 9 * l7] = r[j];
+      for (int j = 1; j < 8; ++j) rr[u][j] = cmul(rr[u][j], w2[j]);
+      // transpose inside each 8-lane group: writer (k1, m2) reg j1 -> reader (k1, j1) reg m2
+      if (P >= 8 || k1l + 8 * u < P) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A[(k1l + 8 * u) * 72 + j + 9 * l7] = rr[u][j];
+      }
+    }
     wave_sync();
 #pragma unroll
-    for (int j = 0; j < 8; ++j) r[j] = A[k1 * 72 + l7 + 9 * j];
-    wave_sync();
-    // ---- pass 3: DFT over m2 -> Z[k1 + 8 j1 + 64 j2]; store in natural order, one pad slot per 8
-    dft8(r);
+    for (int u = 0; u < U; ++u) {
+      const int k1 = min(k1l + 8 * u, P - 1);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) A[k1 + 9 * l7 + 72 * j] = r[j];
+      for (int j = 0; j < 8; ++j) rr[u][j] = A[k1 * 72 + l7 + 9 * j];
+    }
     wave_sync();
-    // ---- real-FFT recombination + magnitude; lane handles k = lane + 64 j and its mirror 512 - k
+    // ---- pass 3: DFT over m2 -> Z[k1 + P (j1 + 8 j2)]; store in natural order, one pad slot per 8
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int u = 0; u < U; ++u) {
+      dft8(rr[u]);
+      if (P >= 8 || k1l + 8 * u < P) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int k = (k1l + 8 * u) + P * (l7 + 8 * j);
+          A[k + (k >> 3)] = rr[u][j];
+        }
+      }
+    }
+    wave_sync();
+    // ---- real-FFT recombination + magnitude; lane handles k = lane + 64 j and its mirror H - k
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
       const int k = lane + 64 * j;
-      if (j < 4 || lane == 0) {
-        const int km = (kHalf - k) & (kHalf - 1);
+      if (j < NR - 1 || lane == 0) {
+        const int km = (H - k) & (H - 1);
         cf zk = A[k + (k >> 3)], zm = A[km + (km >> 3)];
         cf e = {0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y)};
         cf o = {0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x)};
@@ -188,7 +245,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
         cf xk = cadd(e, wo), xm = csub(e, wo);
         // v_sqrt_f32 (1 ulp; the argument is >= 1e-9, never denormal) instead of the 12-instruction IEEE sequence
         mg[k] = __builtin_amdgcn_sqrtf(xk.x * xk.x + xk.y * xk.y + 1e-9f);
-        mg[kHalf - k] = __builtin_amdgcn_sqrtf(xm.x * xm.x + xm.y * xm.y + 1e-9f);
+        mg[H - k] = __builtin_amdgcn_sqrtf(xm.x * xm.x + xm.y * xm.y + 1e-9f);
       }
     }
     wave_sync();
@@ -213,6 +270,10 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
     const int64_t t = t0 + f;
     if (t < T) o[(int64_t)m * T + t] = (t < n_valid) ? tile[m][f] : 0.f;
   }
+}
+
+template <int P> static size_t stft_lds_bytes() {
+  return (size_t)(2 * kWaves * P * 72 + kWaves * (64 * P + 8) + kMaxMelW + kMaxMels * (kFramesPerWG + 1)) * sizeof(float);
 }
 
 }  // namespace dmel
@@ -270,10 +331,11 @@ extern "C" int dmel_stft_plan_create(dmel_stft_plan** out, int sample_rate, int 
                                      int n_mels, double f_min, double f_max, const float* window_host) {
   DMEL_CHECK_ARG(out != nullptr, "plan out pointer is NULL");
   *out = nullptr;
-  if (n_fft != kNfft) {
-    set_error("stft_logmel: n_fft=%d unsupported (gfx950 kernel is specialised for n_fft=1024)", n_fft);
+  if (n_fft != 512 && n_fft != 1024 && n_fft != 2048) {
+    set_error("stft_logmel: n_fft=%d unsupported (the gfx950 kernel is built for n_fft in {512, 1024, 2048})", n_fft);
     return DMEL_EUNSUPPORTED;
   }
+  const int kHalf = n_fft / 2, P = kHalf / 64;
   DMEL_CHECK_ARG(win_length > 0 && win_length <= n_fft, "win_length %d out of range", win_length);
   DMEL_CHECK_ARG(hop_length > 0 && hop_length <= n_fft && (n_fft - hop_length) % 2 == 0,
                  "hop_length %d unsupported (need 0 < hop <= n_fft, n_fft-hop even)", hop_length);
@@ -291,11 +353,11 @@ extern "C" int dmel_stft_plan_create(dmel_stft_plan** out, int sample_rate, int 
     win[woff + n] = window_host ? window_host[n]
                                 : (float)(0.5 - 0.5 * std::cos(2.0 * M_PI * (double)n / (double)win_length));
   }
-  std::vector<cf> winz(kHalf), tw1(8 * 64), tw2(64), twr(257);
+  std::vector<cf> winz(kHalf), tw1((size_t)P * 64), tw2(64), twr(kHalf / 2 + 1);
   for (int n = 0; n < kHalf; ++n) winz[n] = {win[2 * n], win[2 * n + 1]};
-  for (int k = 0; k < 8; ++k)
+  for (int k = 0; k < P; ++k)
     for (int l = 0; l < 64; ++l) {
-      double a = -2.0 * M_PI * (double)(k * l) / 512.0;
+      double a = -2.0 * M_PI * (double)(k * l) / (double)kHalf;
       tw1[k * 64 + l] = {(float)std::cos(a), (float)std::sin(a)};
     }
   for (int j = 0; j < 8; ++j)
@@ -303,8 +365,8 @@ extern "C" int dmel_stft_plan_create(dmel_stft_plan** out, int sample_rate, int 
       double a = -2.0 * M_PI * (double)(j * m) / 64.0;
       tw2[j * 8 + m] = {(float)std::cos(a), (float)std::sin(a)};
     }
-  for (int k = 0; k <= 256; ++k) {
-    double a = -2.0 * M_PI * (double)k / 1024.0;
+  for (int k = 0; k <= kHalf / 2; ++k) {
+    double a = -2.0 * M_PI * (double)k / (double)n_fft;
     twr[k] = {(float)std::cos(a), (float)std::sin(a)};
   }
   build_mel_basis(sample_rate, n_fft, n_mels, f_min, f_max, p->basis);
@@ -319,6 +381,16 @@ extern "C" int dmel_stft_plan_create(dmel_stft_plan** out, int sample_rate, int 
     cnt[m] = hi < 0 ? 0 : hi - lo + 1;
     ptr[m] = (int)packed.size();
     for (int k = 0; k < cnt[m]; ++k) packed.push_back(p->basis[(size_t)m * nb + st[m] + k]);
+  }
+  {  // the n_fft = 2048 instantiation needs 78 KB of dynamic LDS: raise the per-kernel limit (default 64 KB)
+    hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_logmel_kernel<16>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)stft_lds_bytes<16>());
+    if (e1 != hipSuccess && P == 16) {
+      set_error("stft_logmel: cannot reserve %zu bytes of LDS: %s", stft_lds_bytes<16>(), hipGetErrorString(e1));
+      delete p;
+      return (int)e1;
+    }
+    (void)hipGetLastError();
   }
   if (packed.empty()) packed.push_back(0.f);
   if ((int)packed.size() > kMaxMelW) {
@@ -378,8 +450,19 @@ extern "C" int dmel_stft_logmel_f32(const dmel_stft_plan* p, const float* audio,
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope ps("stft_logmel", s, 0.0, (double)B * (4.0 * (double)L + 4.0 * p->n_mels * (double)T));
-    hipLaunchKernelGGL(stft_logmel_kernel, grid, dim3(256), 0, s, tb, audio, row_stride, lengths, out, L, T, p->hop,
-                       p->pad, p->n_mels, p->n_melw);
+    switch (p->n_fft) {
+      case 512:
+        hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(256), stft_lds_bytes<4>(), s, tb, audio, row_stride, lengths, out,
+                           L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+        break;
+      case 1024:
+        hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(256), stft_lds_bytes<8>(), s, tb, audio, row_stride, lengths, out,
+                           L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+        break;
+      default:
+        hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(256), stft_lds_bytes<16>(), s, tb, audio, row_stride, lengths,
+                           out, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+    }
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;

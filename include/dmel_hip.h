@@ -45,7 +45,7 @@ typedef struct dmel_stft_plan dmel_stft_plan;
 
 /* f_max <= 0 means sample_rate/2 (librosa default when fmax=None).  window_host: win_length floats or
  * NULL for the periodic hann window torch.hann_window(win_length) (spectrogram.py:53).
- * Supported: n_fft == 1024, win_length <= n_fft, (n_fft - hop_length) even, n_mels <= 128. */
+ * Supported: n_fft in {512, 1024, 2048}, win_length <= n_fft, (n_fft - hop_length) even, n_mels <= 128. */
 int dmel_stft_plan_create(dmel_stft_plan** plan, int sample_rate, int n_fft, int win_length, int hop_length,
                           int n_mels, double f_min, double f_max, const float* window_host);
 void dmel_stft_plan_destroy(dmel_stft_plan* plan);

@@ -40,7 +40,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
 def test_errors_are_loud_not_fallbacks(L):
     from dmel_codec_amd import _lib
     h = C.c_void_p()
-    rc = L.dmel_stft_plan_create(C.byref(h), 44100, 2048, 2048, 512, 128, 0.0, 0.0, None)
+    rc = L.dmel_stft_plan_create(C.byref(h), 44100, 4096, 4096, 1024, 128, 0.0, 0.0, None)
     assert rc == -2 and b"n_fft" in L.dmel_last_error()
     with pytest.raises(RuntimeError, match="n_fft"):
         _lib.check(rc, "stft_plan_create")

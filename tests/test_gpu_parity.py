@@ -114,10 +114,30 @@ def test_stft_logmel_random(dev, L, hop, B):
     assert torch.equal(y2.cpu() == 0, (ref * mask) == 0)
 
 
+@pytest.mark.parametrize("sr,n_fft,hop,n_mels,win", [(44100, 2048, 512, 128, 2048), (24000, 512, 128, 80, 512),
+                                                    (22050, 1024, 256, 80, 800), (44100, 2048, 441, 100, 1764)])
+def test_stft_other_fft_sizes(dev, sr, n_fft, hop, n_mels, win):
+    """n_fft 512 / 1024 / 2048 (the class default and the 44.1 kHz BigVGAN front end), win_length < n_fft, odd hops."""
+    from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
+    torch.manual_seed(n_fft + hop)
+    L = 30000 + hop // 3
+    x = torch.randn(2, 1, L) * 0.2
+    m = LogMelSpectrogram(sample_rate=sr, n_fft=n_fft, win_length=win, hop_length=hop, n_mels=n_mels, f_min=0, f_max=None)
+    if (n_fft - hop) % 2:
+        with pytest.raises(RuntimeError, match="hop_length"):
+            m(x.to(dev))
+        return
+    y = m(x.to(dev))
+    ref = ref_cpu.stft_logmel(x, sr, n_fft, win, hop, n_mels, 0.0, None)
+    assert y.shape == ref.shape
+    assert rel_err(y, ref) < TOL
+    assert_logmel_close(y, ref, f"n_fft={n_fft}")
+
+
 def test_stft_rejects_unsupported(dev):
     from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
     with pytest.raises(RuntimeError, match="n_fft"):
-        LogMelSpectrogram(sample_rate=44100, n_fft=2048, win_length=2048, hop_length=512, n_mels=128)(torch.zeros(1, 9000, device=dev))
+        LogMelSpectrogram(sample_rate=44100, n_fft=4096, win_length=4096, hop_length=1024, n_mels=128)(torch.zeros(1, 19000, device=dev))
     with pytest.raises(RuntimeError, match="GPU"):
         LogMelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, n_mels=80)(torch.zeros(1, 9000))
     with pytest.raises(RuntimeError, match="reflect pad"):
