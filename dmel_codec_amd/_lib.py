@@ -51,6 +51,7 @@ PROTOTYPES = {
     "dmel_aa_snake_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_wavenet_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmel_wavenet_destroy": (None, [vp]),
+    "dmel_wavenet_set_precision": (C.c_int, [vp, C.c_int]),
     "dmel_wavenet_set_tensor": (C.c_int, [vp, C.c_char_p, vp, i64p, C.c_int]),
     "dmel_wavenet_finalize": (C.c_int, [vp]),
     "dmel_wavenet_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
@@ -69,9 +70,11 @@ PROTOTYPES = {
     "dmel_bigvgan_finalize": (C.c_int, [vp]),
     "dmel_bigvgan_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_bigvgan_set_streams": (C.c_int, [vp, C.c_int]),
+    "dmel_bigvgan_set_precision": (C.c_int, [vp, C.c_int]),
     "dmel_bigvgan_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_conv_create": (C.c_int, [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmel_conv_destroy": (None, [vp]),
+    "dmel_conv_set_precision": (C.c_int, [vp, C.c_int]),
     "dmel_conv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_prof_enable": (C.c_int, [C.c_int]),
     "dmel_prof_reset": (C.c_int, []),

@@ -13,6 +13,9 @@
 
 namespace dmel {
 
+inline bool valid_precision(int p) { return p == DMEL_PRECISION_FP32 || p == DMEL_PRECISION_BF16 || p == DMEL_PRECISION_FP32_MFMA; }
+
+
 void set_error(const char* fmt, ...);
 
 #define DMEL_CHECK_ARG(cond, ...)         \

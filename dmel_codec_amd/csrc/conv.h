@@ -32,6 +32,8 @@ struct PackedConv {
   int Mpad = 0, steps = 0, RP = 0;   // Mpad: packed rows, multiple of 32
   double k_real = 0;       // sum over segments of Cin*taps (algorithmic reduction length)
   DevBuf w, bias;
+  DevBuf w16;              // the same weights rounded to bf16 (RNE), in 32x32x16 MFMA A-fragment order (DMEL_PRECISION_BF16)
+  DevBuf w48;              // the same weights as three exact bf16 pieces (truncation split), same order (split-fp32 kernel)
 };
 
 // get_w(seg, src_row, ci, tap) returns the source weight; get_b(src_row) the bias (0 if none).
@@ -63,6 +65,7 @@ struct ConvRun {
   int len_div = 1;                // lengths index = b / len_div (both in_len and out_len)
   float* skip = nullptr;          // RESSKIP
   int skip_first = 0;
+  int precision = 0;              // DMEL_PRECISION_* (include/dmel_hip.h)
 };
 
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream);
@@ -120,6 +123,45 @@ template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, F
             w[((((size_t)tile * pc.steps + step) * 2 + hf) * 64 + lane) * 4 + j] = get_w(s, sr, ci, tp);
           }
     }
+  }
+  // bf16 images for the 32x32x16 MFMA: [32-row tile][K step][piece][lane 0..63][8]; lane l = 32*h + r holds W[row r][k = 8*h + j].
+  // w16: one piece, round-to-nearest-even.  w48: three pieces by truncation, w = p1 + p2 + p3 exactly (see conv_igemm.hip).
+  {
+    auto bits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
+    auto from_bits = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    auto to_bf16 = [&](float f) -> uint16_t {
+      uint32_t u = bits(f);
+      if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN stays NaN
+      return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                    // round to nearest even
+    };
+    std::vector<uint16_t> w16((size_t)pc.Mpad * pc.steps * kCK, 0), w48((size_t)pc.Mpad * pc.steps * kCK * 3, 0);
+    for (int m = 0; m < pc.Mpad; ++m) {
+      int sr = src_row(m);
+      if (sr < 0) continue;
+      const int tile = m >> 5, r = m & 31;
+      int step = 0;
+      for (int s2 = 0; s2 < d.nseg; ++s2) {
+        const SegDesc& sd = d.seg[s2];
+        int nchunk = (sd.Cin + kCK - 1) / kCK;
+        for (int ch = 0; ch < nchunk; ++ch)
+          for (int tp = 0; tp < sd.taps; ++tp, ++step)
+            for (int k = 0; k < kCK; ++k) {
+              int ci = ch * kCK + k;
+              if (ci >= sd.Cin) continue;
+              const int h = k >> 3, j = k & 7, lane = 32 * h + r;
+              const float v = get_w(s2, sr, ci, tp);
+              w16[(((size_t)tile * pc.steps + step) * 64 + lane) * 8 + j] = to_bf16(v);
+              const float p1 = from_bits(bits(v) & 0xffff0000u), r1 = v - p1;
+              const float p2 = from_bits(bits(r1) & 0xffff0000u), r2 = r1 - p2;
+              const size_t base = ((size_t)tile * pc.steps + step) * 3;
+              w48[((base + 0) * 64 + lane) * 8 + j] = (uint16_t)(bits(p1) >> 16);
+              w48[((base + 1) * 64 + lane) * 8 + j] = (uint16_t)(bits(p2) >> 16);
+              w48[((base + 2) * 64 + lane) * 8 + j] = (uint16_t)(bits(r2) >> 16);
+            }
+      }
+    }
+    DMEL_TRY(pc.w16.upload(w16.data(), w16.size() * sizeof(uint16_t)));
+    DMEL_TRY(pc.w48.upload(w48.data(), w48.size() * sizeof(uint16_t)));
   }
   DMEL_TRY(pc.w.upload(w.data(), w.size() * sizeof(float)));
   DMEL_TRY(pc.bias.upload(b.data(), b.size() * sizeof(float)));

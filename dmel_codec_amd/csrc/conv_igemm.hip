@@ -16,6 +16,7 @@
 // Numerics: exact fp32 fma chains in K order (MI355X_MICROARCH: f32 MFMA == fmaf chain), so results differ
 // from ATen only by summation order.
 #include "conv.h"
+#include <type_traits>
 
 #include <cmath>
 #include <cstdlib>
@@ -37,6 +38,8 @@ struct KArgs {
   int nseg, steps, mtiles;
   int gx, gy, gz, xcd_chunk;   // logical grid (column tiles, m blocks, batch); xcd_chunk > 0: 1-D XCD-chunked launch
   const float* w;
+  const void* w16;
+  const void* w48;
   const float* bias;
   int64_t Tcols;
   int mode, act, C, RP, phases, out_tstride, phase_base, accumulate, len_div, skip_first;
@@ -460,6 +463,308 @@ template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KA
   return launch_h<WM, WN, MT, NT, MODE, 64>(ka, B, mblocks, st);
 }
 
+// -----------------------------------------------------------------------------------------------------------
+// bf16 matrix-core kernels: v_mfma_f32_32x32x16_bf16, fp32 accumulate, fp32 tensors in HBM on both sides.
+//
+//   NP = 3  "split fp32" (DMEL_PRECISION_FP32, the default): every fp32 operand is cut into three bf16 pieces by
+//           truncation, a = a1 + a2 + a3 EXACTLY (3 x 8 significant bits = the 24 of fp32; a1 = a & 0xffff0000,
+//           a2 = (a - a1) & 0xffff0000, a3 = a - a1 - a2, every subtraction exact), and a product is formed from the six
+//           partial products a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, each exact in the fp32 accumulator's input.  The
+//           dropped terms a2b3 + a3b2 + a3b3 are below 2^-21 |ab| (worst case; ~2^-23 typical), i.e. at the level of the
+//           fp32 rounding of the product itself, and far below the accumulation rounding of a K ~ 10^3 reduction.  Six
+//           32-cycle bf16 MFMAs per 32x32x16 block replace eight 64-cycle fp32 MFMAs: 2.67x less matrix-core time for the
+//           same fp32-grade result (tests: same error against the fp64 oracle as the fp32 MFMA kernel).
+//   NP = 1  "bf16 operands" (DMEL_PRECISION_BF16, opt-in): operands rounded to bf16 (RNE), one MFMA per block.  This is the
+//           arithmetic the reference's LM configs ask for when they run the codec under dtype: bfloat16
+//           (config/lm/lm_config.yaml:1,83); it is outside the 1e-4 bar and never the default.
+//
+// x is staged KG*8 channels at a time and kept in LDS as [piece][8-channel group][column][8 x bf16]: the B fragment of any
+// tap is one conflict-free ds_read_b128 per piece, the staging write one ds_write_b128 per (piece, group, column) item.
+// The weight pieces are pre-split on the host and stored in A-fragment order (one coalesced dwordx4 per lane, piece and
+// step, straight from global/L2).  The x loads for chunk c+1 are issued at the first step of chunk c and land in LDS at its
+// last step, so their latency hides behind a whole chunk of MFMAs.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {      // {bf16 bits of lo, bf16 bits of hi} by truncation
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+
+template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO, int NP, int KG>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs a) {
+  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NTHR = 64 * WAVES_M * WAVES_N;
+  constexpr int XS = BN + HALO;
+  constexpr int SUB = KG / 2;                            // 16-channel K steps (per tap) per staged chunk
+  constexpr int NIT = (KG * XS + NTHR - 1) / NTHR;       // (group, column) items per thread per chunk
+  constexpr int PSZ = KG * XS;                           // uint4 per piece
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  uint4* Xb = reinterpret_cast<uint4*>(smem);            // [2][NP][KG][XS] x 16 bytes
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
+  const int h = lane >> 5, l31 = lane & 31;
+  int tile_n, mblk, b;
+  if (!conv_block_coords(a, tile_n, mblk, b)) return;
+  const int q0 = tile_n * BN;
+  const int lb = b / a.len_div;
+
+  floatx16 acc[MT][NT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+  // Weight fragments: wave-uniform (scalar) base per row tile + a 16-byte lane offset, so a step's loads are
+  // global_load_dwordx4 v, v_lane, s[base] offset:piece*1024 with one scalar add per step and no vector address math.
+  const char* wT[MT];
+#pragma unroll
+  for (int mi = 0; mi < MT; ++mi) {
+    const int tile = __builtin_amdgcn_readfirstlane(min(mblk * (BM / 32) + wave_m * MT + mi, a.mtiles - 1));
+    wT[mi] = reinterpret_cast<const char*>(NP == 3 ? a.w48 : a.w16) + (size_t)tile * a.steps * (NP * 1024);
+  }
+  const uint32_t lane16 = lane * 16;
+  auto load_w = [&](uint4 (&dst)[MT][NP], int step) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+      const char* sp = wT[mi] + (size_t)step * (NP * 1024);
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dst[mi][p] = *reinterpret_cast<const uint4*>(sp + p * 1024 + lane16);
+    }
+  };
+  float xr[NIT][8];
+
+  // valid input length per segment, read once (a global load inside the K loop would drain the weight prefetch behind it)
+  auto seg_limit = [&](int sg) {
+    const int tin = (int)a.seg[sg].Tin;
+    return a.seg[sg].in_len ? (int)min(a.seg[sg].in_len[lb], (int64_t)tin) : tin;
+  };
+  const int lim0 = seg_limit(0), lim1 = a.nseg > 1 ? seg_limit(1) : 0;
+  // load_x only issues loads (clamped addresses, no predication, no use of the values): validity is applied by store_x,
+  // a K step of MFMAs later, so no s_waitcnt lands between the loads and the math.  Addresses are a scalar base (batch
+  // item) plus one unsigned 32-bit byte offset per lane: row offsets advance by additions, clamped to the last channel.
+  bool xok[NIT];
+  auto load_x = [&](int sg, int chunk) {
+    const char* xb = reinterpret_cast<const char*>(a.seg[sg].x + (int64_t)b * a.seg[sg].bstride);
+    const int taps = a.seg[sg].taps, dil = a.seg[sg].dil, tstride = a.seg[sg].tstride, Cin = a.seg[sg].Cin;
+    const int wx = BN + (taps - 1) * dil;
+    const int tin = (int)a.seg[sg].Tin;
+    const int lim = sg == 0 ? lim0 : lim1;
+    const int tau0 = q0 * tstride + a.seg[sg].toff - a.seg[sg].pad_left;
+    const uint32_t cs4 = (uint32_t)a.seg[sg].cstride * 4u, last = (uint32_t)(Cin - 1) * cs4;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = min(tid + it * NTHR, KG * XS - 1);
+      const int kg = i / XS, j = i - kg * XS;
+      const int tau = tau0 + j * tstride;
+      xok[it] = (j < wx) && (tau >= 0) && (tau < lim);
+      const uint32_t col = (uint32_t)min(max(tau, 0), tin - 1) * 4u;
+      uint32_t row = (uint32_t)(chunk * (KG * 8) + kg * 8) * cs4;
+#pragma unroll
+      for (int e = 0; e < 8; ++e, row += cs4) xr[it][e] = *reinterpret_cast<const float*>(xb + (min(row, last) + col));
+    }
+  };
+  auto store_x = [&](uint4* dst, int sg, int chunk) {
+    const float scale = a.seg[sg].in_scale;
+    const int Cin = a.seg[sg].Cin;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int i = tid + it * NTHR;
+      if ((KG * XS) % NTHR != 0 && i >= KG * XS) continue;
+      const int c0 = chunk * (KG * 8) + (i / XS) * 8;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (xok[it] && c0 + e < Cin) ? xr[it][e] * scale : 0.f;
+      if constexpr (NP == 1) {
+        bf16x8 p;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) p[e] = (__bf16)v[e];
+        dst[i] = __builtin_bit_cast(uint4, p);
+      } else {
+        uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+          const float r0 = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
+          const float r1 = v[e + 1] - __uint_as_float(__float_as_uint(v[e + 1]) & 0xffff0000u);
+          const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+          const float s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+          p1[e >> 1] = pack_hi16(v[e], v[e + 1]);
+          p2[e >> 1] = pack_hi16(r0, r1);
+          p3[e >> 1] = pack_hi16(s0, s1);
+        }
+        dst[i] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+        dst[PSZ + i] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+        dst[2 * PSZ + i] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+      }
+    }
+  };
+  // scalars of the segment being reduced, kept in SGPRs: read from the kernel arguments inside the loop they cost a
+  // scalar-cache round trip (and an s_waitcnt lgkmcnt(0) that also drains the LDS reads) per K step
+  int cur_taps = a.seg[0].taps, cur_nchunk = a.seg[0].nchunk, cur_dil = a.seg[0].dil;
+  // chunk (sg, ck) -> the chunk staged after it; false when it is the last one
+  auto next_chunk = [&](int sg, int ck, int& nsg, int& nck) -> bool {
+    nsg = sg; nck = ck + 1;
+    if (nck * SUB >= cur_nchunk) { nck = 0; ++nsg; }
+    return nsg < a.nseg;
+  };
+
+  int sg = 0, c16 = 0, tap = 0, xbuf = 0;
+  int psg = 0, pck = 0;          // chunk whose x is on its way to LDS
+  bool pending = false;
+  // Weight fragments are prefetched PD K steps ahead into PD + 1 register sets; the K loop is unrolled so the sets rotate
+  // without copies.  One step of MFMAs (<= 0.5 us) does not cover an L2 hit under load (~1 us): PD = 2.
+  // Weight loads first, x loads last in the prologue: store_x then waits for the youngest load, so nothing is outstanding
+  // when the loop is entered (a prologue load still pending at loop entry forces a static s_waitcnt vmcnt(0) into the loop
+  // body, which then drains the NEXT steps' weight prefetch in every iteration).
+  constexpr int PD = 2;
+  uint4 wa[PD + 1][MT][NP];
+#pragma unroll
+  for (int d = 0; d < PD; ++d)
+    if (d < a.steps) load_w(wa[d], d);
+  load_x(0, 0);
+  store_x(Xb, 0, 0);
+  __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
+  __syncthreads();
+  int cstep = 0;                 // K step inside the staged chunk
+
+  // x fragments are double-buffered in registers as well: the ds_reads of step s + 1 are issued in front of the MFMAs of
+  // step s, so inside one wave the MFMAs run back to back (only the first step after a buffer flip waits for LDS).
+  bf16x8 bv[2][NT][NP];
+  auto read_b = [&](bf16x8 (&dst)[NT][NP], int c16_, int tap_) {
+    const uint4* xp = Xb + xbuf * (NP * PSZ) + ((c16_ % SUB) * 2 + h) * XS + wave_n * (NT * 32) + l31 + tap_ * cur_dil;
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int p = 0; p < NP; ++p) dst[ni][p] = __builtin_bit_cast(bf16x8, xp[p * PSZ + ni * 32]);
+  };
+  read_b(bv[0], 0, 0);
+
+  // Staging of the NEXT chunk is kept off the barrier's critical path: its global loads are issued at the chunk's first
+  // K step, converted and written into the idle LDS buffer one step later (the buffer was released by the barrier that
+  // opened this chunk), and the barrier that closes the chunk has nothing but MFMAs in front of it.
+  // R = s mod 6 at compile time: weight set R % 3 is consumed and (R + 2) % 3 filled, x fragment set R % 2 consumed.
+  auto k_step = [&](auto R, int s) {
+    constexpr int r = decltype(R)::value;
+    uint4 (&use)[MT][NP] = wa[r % 3];
+    bf16x8 (&bcur)[NT][NP] = bv[r % 2];
+    bf16x8 (&bnxt)[NT][NP] = bv[(r + 1) % 2];
+    int nsg = sg, nc16 = c16, ntap = tap + 1;
+    bool newx = false;
+    if (ntap == cur_taps) {
+      ntap = 0;
+      ++nc16;
+      if (nc16 == cur_nchunk) { nc16 = 0; ++nsg; newx = true; }
+      else newx = (nc16 % SUB) == 0;
+    }
+    const bool has_next = s + 1 < a.steps;
+    if (s + PD < a.steps) load_w(wa[(r + 2) % 3], s + PD);
+    if (cstep == 0) {
+      pending = next_chunk(sg, c16 / SUB, psg, pck);
+      if (pending) load_x(psg, pck);
+    }
+    if (has_next && !newx) read_b(bnxt, nc16, ntap);
+    const bool stage_now = pending && (cstep == 1 || newx);    // second step of the chunk, or its only one
+    if constexpr (NP == 1) {
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use[mi][0]), bcur[ni][0], acc[mi][ni], 0, 0, 0);
+    } else {
+      // smallest partial products first; the MT*NT independent accumulators separate dependent MFMAs
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use[mi][PA[t]]), bcur[ni][PB[t]],
+                                                                  acc[mi][ni], 0, 0, 0);
+    }
+    if (stage_now) {
+      store_x(Xb + (xbuf ^ 1) * (NP * PSZ), psg, pck);
+      pending = false;
+    }
+    ++cstep;
+    if (has_next && newx) {
+      __syncthreads();
+      xbuf ^= 1;
+      cstep = 0;
+      if (nsg != sg) { cur_taps = a.seg[nsg].taps; cur_nchunk = a.seg[nsg].nchunk; cur_dil = a.seg[nsg].dil; }
+      read_b(bnxt, nc16, ntap);
+    }
+    sg = nsg; c16 = nc16; tap = ntap;
+  };
+  static_assert(PD == 2, "the rotation below is written out for three weight sets and two x sets");
+  for (int s = 0; s < a.steps; s += 6) {
+    k_step(std::integral_constant<int, 0>{}, s);
+    if (s + 1 < a.steps) k_step(std::integral_constant<int, 1>{}, s + 1);
+    if (s + 2 < a.steps) k_step(std::integral_constant<int, 2>{}, s + 2);
+    if (s + 3 < a.steps) k_step(std::integral_constant<int, 3>{}, s + 3);
+    if (s + 4 < a.steps) k_step(std::integral_constant<int, 4>{}, s + 4);
+    if (s + 5 < a.steps) k_step(std::integral_constant<int, 5>{}, s + 5);
+  }
+  conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
+}
+
+template <int WM, int WN, int MT, int NT, int MODE, int HALO, int NP, int KG>
+static int launch_b16k(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+  constexpr int BN = WN * NT * 32;
+  constexpr size_t lds = (size_t)2 * NP * KG * (BN + HALO) * 16;
+  static_assert(lds <= 64 * 1024, "bf16 conv tile exceeds the default dynamic LDS limit");
+  KArgs k2 = ka;
+  dim3 grid;
+  DMEL_TRY(conv_grid(k2, (int)((ka.Tcols + BN - 1) / BN), mblocks, B, grid));
+  hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, MODE, HALO, NP, KG>), grid, dim3(64 * WM * WN), lds, st, k2);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+template <int WM, int WN, int MT, int NT, int MODE, int NP> static int launch_b16(const KArgs& ka, int B, int mblocks, hipStream_t st) {
+  int halo = 0;
+  for (int s = 0; s < ka.nseg; ++s) halo = std::max(halo, (ka.seg[s].taps - 1) * ka.seg[s].dil);
+  // 1x1 convolutions stage 32 channels per barrier (two K steps); everything else 16 (taps K steps)
+  constexpr int KG0 = (WN * NT * 32 >= 256 && NP == 3) ? 2 : 4;       // keep the widest tile inside 64 KiB of LDS
+  if (halo == 0) return launch_b16k<WM, WN, MT, NT, MODE, 0, NP, KG0>(ka, B, mblocks, st);
+  return launch_b16k<WM, WN, MT, NT, MODE, 64, NP, 2>(ka, B, mblocks, st);
+}
+
+template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int tile, int B, hipStream_t st) {
+  const int bm[6] = {128, 128, 64, 32, 128, 64};
+  // bf16 tiles: 0: 128x128 (2,2,2,2), 1: 128x96 (4,1,1,3), 2: 64x128 (2,2,1,2), 3: 32x256 (1,4,1,2), 4: 128x128 (4,1,1,4),
+  // 5: 64x128 (2,1,1,4)
+  const int mblocks = (ka.mtiles * 32 + bm[tile] - 1) / bm[tile];
+  switch (tile) {
+    case 0: return launch_b16<2, 2, 2, 2, MODE, NP>(ka, B, mblocks, st);
+    case 1: return launch_b16<4, 1, 1, 3, MODE, NP>(ka, B, mblocks, st);
+    case 2: return launch_b16<2, 2, 1, 2, MODE, NP>(ka, B, mblocks, st);
+    case 3: return launch_b16<1, 4, 1, 2, MODE, NP>(ka, B, mblocks, st);
+    case 4: return launch_b16<4, 1, 1, 4, MODE, NP>(ka, B, mblocks, st);
+    default: return launch_b16<2, 1, 1, 4, MODE, NP>(ka, B, mblocks, st);
+  }
+}
+
+// Measured on MI355X (tools/bench_conv.py, DMEL_CONV_TILE_BF16 sweep): long rows of >= 128 output channels run best with
+// one 32-row strip per wave (4: weights fetched once per block), short ones with the 96-column tile (less padding at
+// T = 92 / 736); 64-row problems on 64x128, 32-row problems on 32x256.
+static int pick_tile_bf16(int mtiles, int64_t T) {
+  static int forced = [] { const char* e = getenv("DMEL_CONV_TILE_BF16"); return e ? atoi(e) : -1; }();
+  if (forced >= 0 && forced < 6) return forced;
+  if (mtiles >= 4) return T > 2048 ? 4 : 1;
+  if (mtiles >= 2) return 2;
+  return 3;
+}
+
+template <int NP> static int launch_bf16_any(const KArgs& ka, EpiMode mode, int B, int64_t Tcols, hipStream_t st) {
+  const int t16 = pick_tile_bf16(ka.mtiles, Tcols);
+  switch (mode) {
+    case EPI_LINEAR: return launch_mode_bf16<EPI_LINEAR, NP>(ka, t16, B, st);
+    case EPI_GATE: return launch_mode_bf16<EPI_GATE, NP>(ka, t16, B, st);
+    default: return launch_mode_bf16<EPI_RESSKIP, NP>(ka, t16, B, st);
+  }
+}
+
 // ---- tile selection -------------------------------------------------------------------------------------------
 // The kernel is MFMA-bound, so a launch costs (rounds of workgroups over the 256 CUs) x (tile area) / (how well a wave
 // of that shape keeps the pipe fed).  Padding waste and the last, partly filled round are what the choice trades.
@@ -555,7 +860,7 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   }
   DMEL_CHECK_ARG(r.y != nullptr && r.B > 0 && r.Tcols > 0, "conv: bad output/batch/length");
   DMEL_CHECK_ARG(d.mode != EPI_RESSKIP || r.skip != nullptr, "conv: skip buffer missing");
-  ka.w = pc.w.as<float>(); ka.bias = pc.bias.as<float>();
+  ka.w = pc.w.as<float>(); ka.w16 = pc.w16.p; ka.w48 = pc.w48.p; ka.bias = pc.bias.as<float>();
   ka.Tcols = r.Tcols; ka.mode = d.mode; ka.act = r.act; ka.C = d.C; ka.RP = pc.RP; ka.phases = d.phases;
   ka.out_tstride = r.out_tstride; ka.phase_base = r.phase_base; ka.accumulate = r.accumulate;
   ka.len_div = r.len_div > 0 ? r.len_div : 1; ka.skip_first = r.skip_first; ka.out_div = r.out_div;
@@ -567,6 +872,12 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   ka.mtiles = pc.Mpad / 32;
   const double rows_real = (d.mode == EPI_LINEAR ? (double)d.C * d.phases : 2.0 * d.C);
   ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, 0.0);
+  static const int native_fp32 = [] { const char* e = getenv("DMEL_CONV_FP32_MFMA"); return e ? atoi(e) : 0; }();
+  if (r.precision == DMEL_PRECISION_BF16) return launch_bf16_any<1>(ka, d.mode, r.B, r.Tcols, stream);
+  // fp32: the split kernel wins wherever there is a reduction worth the staging (measured: everything but the 32-row,
+  // K < 128 convolutions of the last vocoder stage, which are bound by their HBM traffic either way)
+  if (r.precision == DMEL_PRECISION_FP32 && !native_fp32 && !(ka.mtiles == 1 && pc.k_real < 128))
+    return launch_bf16_any<3>(ka, d.mode, r.B, r.Tcols, stream);
   const int tile = pick_tile(ka.mtiles, r.Tcols, r.B);
   switch (d.mode) {
     case EPI_LINEAR: return launch_mode<EPI_LINEAR>(ka, tile, r.B, stream);
@@ -583,7 +894,14 @@ using namespace dmel;
 struct dmel_conv {
   PackedConv pc;
   int Cout, Cin, k, dil;
+  int precision = 0;
 };
+
+extern "C" int dmel_conv_set_precision(dmel_conv* c, int precision) {
+  DMEL_CHECK_ARG(c && valid_precision(precision), "conv_set_precision: not a DMEL_PRECISION_* value");
+  c->precision = precision;
+  return DMEL_OK;
+}
 
 extern "C" int dmel_conv_create(dmel_conv** out, const float* w_host, const float* bias_host, int Cout, int Cin, int k,
                                 int dilation) {
@@ -609,5 +927,6 @@ extern "C" int dmel_conv_forward(const dmel_conv* c, const float* x, float* y, i
   ConvRun r;
   r.seg[0].x = x; r.seg[0].bstride = (int64_t)c->Cin * T; r.seg[0].cstride = T; r.seg[0].Tin = T;
   r.B = B; r.Tcols = T; r.y = y; r.y_bs = (int64_t)c->Cout * T; r.y_cs = T; r.Tout = T;
+  r.precision = c->precision;
   return launch_conv(c->pc, r, (hipStream_t)stream);
 }

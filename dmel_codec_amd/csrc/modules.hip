@@ -92,7 +92,9 @@ struct dmel_wavenet {
   bool has_in = false, has_out = false;
   PackedConv in_proj, skip_proj, out_proj;
   std::vector<PackedConv> gate, resskip;
+  int precision = 0;
 };
+
 
 extern "C" int dmel_wavenet_create(dmel_wavenet** out, int input_channels, int output_channels, int residual_channels,
                                    int residual_layers, int dilation_cycle, int condition_channels) {
@@ -110,6 +112,11 @@ extern "C" int dmel_wavenet_create(dmel_wavenet** out, int input_channels, int o
   return DMEL_OK;
 }
 extern "C" void dmel_wavenet_destroy(dmel_wavenet* m) { delete m; }
+extern "C" int dmel_wavenet_set_precision(dmel_wavenet* m, int precision) {
+  DMEL_CHECK_ARG(m && valid_precision(precision), "wavenet_set_precision: not a DMEL_PRECISION_* value");
+  m->precision = precision;
+  return DMEL_OK;
+}
 extern "C" int dmel_wavenet_set_tensor(dmel_wavenet* m, const char* key, const float* data, const int64_t* shape, int ndim) {
   DMEL_CHECK_ARG(m, "NULL handle");
   m->ready = false;
@@ -200,6 +207,7 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
   if (m->has_in) {  // wavenet.py:205-207: 1x1 projection + SiLU
     ConvRun r = run_1seg(x, m->Cin, T, xb, C, T, N);
     r.seg[0].in_len = in_lengths; r.len_div = div; r.act = ACT_SILU;
+    r.precision = m->precision;
     DMEL_TRY(launch_conv(m->in_proj, r, st));
   } else {
     DMEL_TRY(launch_masked_copy(x, xb, in_lengths, div, N, C, T, st));
@@ -209,9 +217,11 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
     if (m->Ccond) {
       g.seg[1].x = condition; g.seg[1].bstride = (int64_t)m->Ccond * T; g.seg[1].cstride = T; g.seg[1].Tin = T;
     }
+    g.precision = m->precision;
     DMEL_TRY(launch_conv(m->gate[i], g, st));
     ConvRun r = run_1seg(zb, C, T, xb, C, T, N);
     r.skip = sb; r.skip_first = (i == 0);
+    r.precision = m->precision;
     DMEL_TRY(launch_conv(m->resskip[i], r, st));
   }
   {  // wavenet.py:218-223
@@ -219,11 +229,13 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
     r.seg[0].in_scale = (float)(1.0 / std::sqrt((double)m->L));
     if (m->has_out) r.act = ACT_SILU;
     else { r.out_len = out_lengths; r.len_div = div; }
+    r.precision = m->precision;
     DMEL_TRY(launch_conv(m->skip_proj, r, st));
     if (m->has_out) {
       ConvRun o = run_1seg(tb, C, T, y, m->Cout, T, N);
       o.out_len = out_lengths; o.len_div = div;
-      DMEL_TRY(launch_conv(m->out_proj, o, st));
+      o.precision = m->precision;
+    DMEL_TRY(launch_conv(m->out_proj, o, st));
     }
   }
   return DMEL_OK;
@@ -478,6 +490,7 @@ struct dmel_bigvgan {
   hipStream_t side[kSide] = {nullptr, nullptr};
   hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr}, ev_chain[3] = {nullptr, nullptr, nullptr};
   bool multi = false;
+  int precision = 0;
   ~dmel_bigvgan() {
     for (int i = 0; i < kSide; ++i) {
       if (side[i]) (void)hipStreamDestroy(side[i]);
@@ -524,6 +537,11 @@ extern "C" int dmel_bigvgan_create(dmel_bigvgan** out, const dmel_bigvgan_config
   return DMEL_OK;
 }
 extern "C" void dmel_bigvgan_destroy(dmel_bigvgan* m) { delete m; }
+extern "C" int dmel_bigvgan_set_precision(dmel_bigvgan* m, int precision) {
+  DMEL_CHECK_ARG(m && valid_precision(precision), "bigvgan_set_precision: not a DMEL_PRECISION_* value");
+  m->precision = precision;
+  return DMEL_OK;
+}
 extern "C" int dmel_bigvgan_set_tensor(dmel_bigvgan* m, const char* key, const float* data, const int64_t* shape, int ndim) {
   DMEL_CHECK_ARG(m, "NULL handle");
   m->ready = false;
@@ -690,6 +708,7 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
 
   {  // conv_pre (bigvgan.py:369)
     ConvRun r = run_1seg(mel, c.num_mels, T, x, c.upsample_initial_channel, T, B);
+    r.precision = m->precision;
     DMEL_TRY(launch_conv(m->conv_pre, r, st));
   }
   int64_t Tc = T;
@@ -700,7 +719,8 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
     for (int half = 0; half < 2; ++half) {  // transposed conv as two phase groups (bigvgan.py:371-374)
       ConvRun r = run_1seg(x, us.Cin, Tc, xu, us.Cout, Tn, B);
       r.Tcols = Tc; r.out_tstride = us.u; r.phase_base = half * (us.u / 2); r.Tout = Tn;
-      DMEL_TRY(launch_conv(half == 0 ? us.lo : us.hi, r, st));
+      r.precision = m->precision;
+    DMEL_TRY(launch_conv(half == 0 ? us.lo : us.hi, r, st));
     }
     ch = us.Cout;
     Tc = Tn;
@@ -718,7 +738,8 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
       for (int l = 0; l < 3; ++l) {
         DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps, logscale, B, ch, Tc, sj));
         ConvRun r1 = run_1seg(uj, ch, Tc, vj, ch, Tc, B);
-        DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
+        r1.precision = m->precision;
+    DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
         DMEL_TRY(launch_aa_snake(vj, uj, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps, logscale, B, ch, Tc, sj));
         ConvRun r2 = run_1seg(uj, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
         r2.res = xin; r2.res_bs = bs; r2.res_cs = Tc;
@@ -728,7 +749,8 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
           if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
           if (multi && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
         }
-        DMEL_TRY(launch_conv(ab.c2[l], r2, sj));
+        r2.precision = m->precision;
+    DMEL_TRY(launch_conv(ab.c2[l], r2, sj));
         if (l == 2 && multi && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_chain[j], sj));
         xin = xj;
       }

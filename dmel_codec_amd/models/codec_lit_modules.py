@@ -66,6 +66,14 @@ class VQGAN(nn.Module):
         if dmel_groups <= 0:
             raise NotImplementedError("only the dMel layout (dmel_groups > 0) works in the reference (SURVEY.md App. C)")
 
+    def set_decode_precision(self, precision) -> None:
+        """Opt-in throughput mode for decode(): "bf16" runs the decoder WaveNet and the vocoder convolutions with
+        bf16-rounded operands and fp32 accumulation (tensors stay fp32); "fp32" (default) is the parity path.
+        encode() is not affected: the ids are the interchange format and stay bit-stable."""
+        for m in (self.decoder, self.vocoder):
+            if m is not None:
+                m.set_precision(precision)
+
     @property
     def device(self) -> torch.device:
         return self.quality_projection.weight.device

@@ -17,12 +17,14 @@ class NativeModule(nn.Module):
     _destroy_symbol = ""
     _set_symbol = ""
     _finalize_symbol = ""
+    _precision_symbol = ""   # modules whose convolutions have the opt-in bf16 mode name their dmel_*_set_precision here
 
     def __init__(self):
         super().__init__()
         self._handle: Optional[int] = None
         self._handle_versions = None
         self._ws = _lib.Workspace()
+        self._precision = 0
 
     # -- handle life cycle ---------------------------------------------------------------------
     def _native_state(self) -> dict:
@@ -43,11 +45,26 @@ class NativeModule(nn.Module):
             try:
                 _lib.set_tensors(getattr(L, self._set_symbol), h, self._native_state(), type(self).__name__)
                 _lib.check(getattr(L, self._finalize_symbol)(h), f"{type(self).__name__}.finalize")
+                if self._precision:
+                    _lib.check(getattr(L, self._precision_symbol)(h, self._precision), f"{type(self).__name__}.set_precision")
             except Exception:
                 getattr(L, self._destroy_symbol)(h)
                 raise
             self._handle, self._handle_versions = h, ver
         return self._handle
+
+    def set_precision(self, precision) -> None:
+        """"fp32" (default; the parity path) or "bf16": convolution operands rounded to bf16, fp32 accumulation, fp32
+        tensors everywhere else (include/dmel_hip.h, DMEL_PRECISION_*).  Accepts the strings, torch dtypes or 0 / 1."""
+        table = {"fp32": 0, "float32": 0, torch.float32: 0, 0: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1, 1: 1}
+        if precision not in table:
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if table[precision] and not self._precision_symbol:
+            raise NotImplementedError(f"{type(self).__name__} has no bf16 mode")
+        self._precision = table[precision]
+        if self._handle is not None and self._precision_symbol:
+            _lib.check(getattr(_lib.lib(), self._precision_symbol)(self._handle, self._precision),
+                       f"{type(self).__name__}.set_precision")
 
     def _free_native(self):
         if getattr(self, "_handle", None) is not None and _lib._lib is not None:

@@ -91,6 +91,7 @@ class BigVGAN(NativeModule):
     _destroy_symbol = "dmel_bigvgan_destroy"
     _set_symbol = "dmel_bigvgan_set_tensor"
     _finalize_symbol = "dmel_bigvgan_finalize"
+    _precision_symbol = "dmel_bigvgan_set_precision"
 
     def __init__(self, h: AttrDict = None, use_cuda_kernel: bool = False, h_path=None, ckpt_path=None):
         super().__init__()

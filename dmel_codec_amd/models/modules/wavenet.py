@@ -59,6 +59,7 @@ class WaveNet(NativeModule):
     _destroy_symbol = "dmel_wavenet_destroy"
     _set_symbol = "dmel_wavenet_set_tensor"
     _finalize_symbol = "dmel_wavenet_finalize"
+    _precision_symbol = "dmel_wavenet_set_precision"
 
     def __init__(self, input_channels: Optional[int] = None, output_channels: Optional[int] = None,
                  residual_channels: int = 512, residual_layers: int = 20, dilation_cycle: Optional[int] = 4,

@@ -32,6 +32,20 @@ extern "C" {
 #define DMEL_EUNSUPPORTED (-2)
 #define DMEL_EMISSING (-3)
 
+/* Arithmetic of the convolutions of a handle (dmel_*_set_precision).  Tensors are fp32 in HBM in every mode.
+ *  FP32 (default, the parity path): fp32-grade products, fp32 accumulation; results within 1e-4 of the reference run in
+ *      fp32.  The library is free to form the products either on the fp32 MFMA or from an exact three-way bf16 split of
+ *      both operands on the bf16 matrix cores (six partial products, dropped terms < 2^-21 relative; DESIGN.md "split
+ *      fp32") -- both meet the same error bound against an fp64 evaluation and tests hold them to it.
+ *  FP32_MFMA: force the native v_mfma_f32_32x32x2_f32 kernel (every product one exact fp32 fma).
+ *  BF16: opt-in throughput mode, the library-side equivalent of running the reference's codec under dtype: bfloat16
+ *      (config/lm/lm_config.yaml:1,83; models/lm_lit_modules.py:52-55): weights and staged activations rounded to bf16
+ *      (nearest-even), fp32 accumulation; activations, biases, residuals and the quantizer stay fp32.  More accurate than
+ *      the reference's bf16 autocast, but NOT within the 1e-4 bar. */
+#define DMEL_PRECISION_FP32 0
+#define DMEL_PRECISION_BF16 1
+#define DMEL_PRECISION_FP32_MFMA 2
+
 const char* dmel_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
 int dmel_abi_version(void);
@@ -84,6 +98,7 @@ typedef struct dmel_wavenet dmel_wavenet;
 int dmel_wavenet_create(dmel_wavenet** m, int input_channels /*0 = same as residual*/, int output_channels /*0 = none*/,
                         int residual_channels, int residual_layers, int dilation_cycle, int condition_channels /*0 = none*/);
 void dmel_wavenet_destroy(dmel_wavenet* m);
+int dmel_wavenet_set_precision(dmel_wavenet* m, int precision);   /* DMEL_PRECISION_*; may be changed between forwards */
 int dmel_wavenet_set_tensor(dmel_wavenet* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
 int dmel_wavenet_finalize(dmel_wavenet* m);
 size_t dmel_wavenet_workspace_bytes(const dmel_wavenet* m, int N, int64_t T);
@@ -144,6 +159,7 @@ size_t dmel_bigvgan_workspace_bytes(const dmel_bigvgan* m, int B, int64_t T);
  * activations of one block then overlap the MFMA-bound convolutions of another).  Results are identical.  A handle's
  * forward is not re-entrant from two host threads at once (it owns the fork/join events). */
 int dmel_bigvgan_set_streams(dmel_bigvgan* m, int n_streams);
+int dmel_bigvgan_set_precision(dmel_bigvgan* m, int precision);   /* DMEL_PRECISION_*; conv_post (C -> 1) always runs in fp32 */
 /* mel (B, num_mels, T) -> audio (B, 1, T * prod(upsample_rates)) */
 int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, float* audio, int B, int64_t T,
                          void* workspace, size_t workspace_bytes, void* stream);
@@ -156,6 +172,7 @@ typedef struct dmel_conv dmel_conv;
 int dmel_conv_create(dmel_conv** c, const float* w_host, const float* bias_host /*nullable*/, int Cout, int Cin, int k,
                      int dilation);
 void dmel_conv_destroy(dmel_conv* c);
+int dmel_conv_set_precision(dmel_conv* c, int precision);
 int dmel_conv_forward(const dmel_conv* c, const float* x, float* y, int B, int64_t T, void* stream);
 
 /* Timing hook used by bench.py: when enabled, every launch of the named kernel family on `stream` is

@@ -497,3 +497,98 @@ def test_errors_on_bad_shapes(dev):
                      noise=torch.zeros(1, 560, 15, device=dev))
     with pytest.raises(ValueError, match="Vocoder"):
         codec.decode(torch.zeros(1, 8, 4, dtype=torch.int32, device=dev), torch.tensor([4], device=dev), return_audios=True)
+
+
+# ------------------------------------------------------------------------------------ opt-in bf16 operand mode
+# Not the parity path: these tests pin what the mode IS (operands rounded to bf16 with round-to-nearest-even, exact
+# products, fp32 accumulation) and bound how far it moves the outputs, so it cannot drift silently.
+@pytest.mark.parametrize("Cout,Cin,k,dil,T,B", [
+    (32, 32, 3, 1, 100, 2), (32, 32, 11, 5, 300, 2), (64, 64, 7, 3, 257, 1), (128, 128, 3, 5, 130, 2),
+    (256, 256, 11, 1, 96, 1), (140, 70, 3, 8, 93, 3), (512, 100, 7, 1, 92, 2), (70, 280, 1, 1, 23, 5),
+    (100, 700, 1, 1, 92, 1), (33, 17, 5, 2, 65, 1), (128, 48, 7, 9, 2500, 1),
+])
+def test_conv_bf16_operand_mode(dev, Cout, Cin, k, dil, T, B):
+    from dmel_codec_amd import _lib
+    torch.manual_seed(Cout * 1000 + Cin + k)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    b = torch.randn(Cout) * 0.1
+    x = torch.randn(B, Cin, T)
+    ref = F.conv1d(x.bfloat16().double(), w.bfloat16().double(), b.double(), dilation=dil, padding=dil * (k - 1) // 2)
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), b.data_ptr(), Cout, Cin, k, dil))
+    try:
+        assert L.dmel_conv_set_precision(h, 7) < 0
+        _lib.check(L.dmel_conv_set_precision(h, 1))
+        xd = x.to(dev)
+        y = torch.empty(B, Cout, T, device=dev)
+        _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert rel_err(y, ref) < 1e-5          # only fp32 accumulation order separates the two
+        _lib.check(L.dmel_conv_set_precision(h, 0))                     # and back: the fp32 path is untouched
+        _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+        assert rel_err(y, F.conv1d(x, w, b, dilation=dil, padding=dil * (k - 1) // 2)) < 2e-5
+    finally:
+        L.dmel_conv_destroy(h)
+
+
+def test_decode_bf16_mode_stays_close_to_fp32(dev):
+    codec = make_codec(320, n_mels=80, dmel_groups=8, decoder_layers=6, encoder_layers=2)
+    with torch.no_grad():
+        codec.vocoder.conv_post.weight_g.fill_(0.02)     # keep the random vocoder out of tanh saturation: errors stay readable
+    codec = codec.to(dev)
+    B, T4 = 3, 40
+    gen = torch.Generator().manual_seed(99)
+    ids = torch.randint(0, 175, (B, 8, T4), generator=gen, dtype=torch.int32).to(dev)
+    flen = torch.tensor([T4, 17, 33], device=dev)
+    noise = torch.randn(B, 560, T4 * 4, generator=gen).to(dev)
+    audio32, mel32 = codec.decode(ids, flen, return_audios=True, noise=noise)
+    codec.set_decode_precision("bf16")
+    audio16, mel16 = codec.decode(ids, flen, return_audios=True, noise=noise)
+    assert not torch.equal(mel16, mel32)                      # the mode really ran
+    assert rel_err(mel16, mel32) < 1e-2, rel_err(mel16, mel32)
+    assert rel_err(audio16, audio32) < 0.15, rel_err(audio16, audio32)   # random deep net: amplifies; a trained vocoder does not
+    assert torch.all(mel16[1, :, 17 * 4:] == 0)               # masks are applied exactly as in fp32
+    # encode() ignores the mode: ids stay bit-stable
+    a = torch.randn(2, 1, 12000, generator=gen).to(dev) * 0.1
+    l = torch.tensor([12000, 9000], device=dev)
+    ids16, _ = codec.encode(a, l)
+    codec.set_decode_precision("fp32")
+    ids32, _ = codec.encode(a, l)
+    assert torch.equal(ids16, ids32)
+    audio_back, mel_back = codec.decode(ids, flen, return_audios=True, noise=noise)
+    assert torch.equal(mel_back, mel32) and torch.equal(audio_back, audio32)
+    with pytest.raises(ValueError):
+        codec.decoder.set_precision("fp16")
+    with pytest.raises(NotImplementedError):
+        codec.quantizer.set_precision("bf16")
+
+
+@pytest.mark.parametrize("Cout,Cin,k,dil,T,B", [(256, 256, 7, 3, 736, 2), (128, 128, 11, 5, 3000, 1), (1120, 560, 3, 2, 92, 2),
+                                                (64, 64, 7, 1, 1500, 2), (32, 32, 11, 5, 4000, 1), (140, 70, 3, 4, 93, 4)])
+def test_split_fp32_conv_is_fp32_grade(dev, Cout, Cin, k, dil, T, B):
+    """The default fp32 path forms products from an exact 3-way bf16 split on the bf16 matrix cores.  Against an fp64
+    evaluation its error must be no worse than that of the native fp32 MFMA kernel (DMEL_PRECISION_FP32_MFMA) by more than
+    rounding noise, and both must sit at fp32 accumulation level."""
+    from dmel_codec_amd import _lib
+    torch.manual_seed(Cout + Cin + k + T)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    b = torch.randn(Cout) * 0.1
+    x = torch.randn(B, Cin, T) * torch.logspace(-3, 1, Cin)[None, :, None]      # channels spanning four decades
+    ref = F.conv1d(x.double(), w.double(), b.double(), dilation=dil, padding=dil * (k - 1) // 2)
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), b.data_ptr(), Cout, Cin, k, dil))
+    try:
+        xd = x.to(dev)
+        errs = {}
+        for name, mode in (("split", 0), ("native", 2)):
+            _lib.check(L.dmel_conv_set_precision(h, mode))
+            y = torch.empty(B, Cout, T, device=dev)
+            _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            errs[name] = rel_err(y, ref)
+        assert errs["native"] < 2e-6 and errs["split"] < 2e-6, errs
+        assert errs["split"] < 1.5 * errs["native"] + 1e-7, errs
+    finally:
+        L.dmel_conv_destroy(h)

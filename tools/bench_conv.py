@@ -27,6 +27,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
+    ap.add_argument("--precision", type=int, default=0, help="0 fp32 (split-bf16 kernel), 1 bf16 operands, 2 fp32 on the native fp32 MFMA")
+    ap.add_argument("--check", action="store_true", help="compare with torch conv1d (operands rounded the same way)")
     args = ap.parse_args()
     L = _lib.lib()
     dev = torch.device("cuda:0")
@@ -37,6 +39,7 @@ def main():
         b = torch.randn(Cout)
         h = C.c_void_p()
         _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), b.data_ptr(), Cout, Cin, k, dil))
+        _lib.check(L.dmel_conv_set_precision(h, args.precision))
         x = torch.randn(B, Cin, T, device=dev)
         y = torch.empty(B, Cout, T, device=dev)
         st = _lib.stream_ptr()
@@ -51,6 +54,13 @@ def main():
         ms = e0.elapsed_time(e1) / args.iters
         fl = 2.0 * B * T * Cout * Cin * k
         print(f"{name:12s} M={Cout:5d} K={Cin * k:5d} N={T}x{B}  {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s", flush=True)
+        if args.check:
+            wd, xd = w.to(dev), x[:2]
+            if args.precision == 1:
+                wd, xd = wd.bfloat16().float(), xd.bfloat16().float()
+            ref = torch.nn.functional.conv1d(xd.double(), wd.double(), b.to(dev).double(), dilation=dil, padding=dil * (k - 1) // 2)
+            err = (y[:2].double() - ref).abs().max().item() / ref.abs().max().item()
+            print(f"             max err / max |ref| = {err:.2e}", flush=True)
         L.dmel_conv_destroy(h)
 
 
