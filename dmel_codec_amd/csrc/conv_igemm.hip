@@ -484,6 +484,9 @@ template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KA
 // step, straight from global/L2).  The x loads for chunk c+1 are issued at the first step of chunk c and land in LDS at its
 // last step, so their latency hides behind a whole chunk of MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#ifndef DMEL_PD
+#define DMEL_PD 2   // weight prefetch distance in K steps
+#endif
 
 __device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {      // {bf16 bits of lo, bf16 bits of hi} by truncation
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
@@ -616,7 +619,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
   // Weight loads first, x loads last in the prologue: store_x then waits for the youngest load, so nothing is outstanding
   // when the loop is entered (a prologue load still pending at loop entry forces a static s_waitcnt vmcnt(0) into the loop
   // body, which then drains the NEXT steps' weight prefetch in every iteration).
-  constexpr int PD = 2;
+  constexpr int PD = DMEL_PD;
   uint4 wa[PD + 1][MT][NP];
 #pragma unroll
   for (int d = 0; d < PD; ++d)
@@ -645,7 +648,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
   // R = s mod 6 at compile time: weight set R % 3 is consumed and (R + 2) % 3 filled, x fragment set R % 2 consumed.
   auto k_step = [&](auto R, int s) {
     constexpr int r = decltype(R)::value;
-    uint4 (&use)[MT][NP] = wa[r % 3];
+    uint4 (&use)[MT][NP] = wa[r % (PD + 1)];
     bf16x8 (&bcur)[NT][NP] = bv[r % 2];
     bf16x8 (&bnxt)[NT][NP] = bv[(r + 1) % 2];
     int nsg = sg, nc16 = c16, ntap = tap + 1;
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
       else newx = (nc16 % SUB) == 0;
     }
     const bool has_next = s + 1 < a.steps;
-    if (s + PD < a.steps) load_w(wa[(r + 2) % 3], s + PD);
+    if (s + PD < a.steps) load_w(wa[(r + PD) % (PD + 1)], s + PD);
     if (cstep == 0) {
       pending = next_chunk(sg, c16 / SUB, psg, pck);
       if (pending) load_x(psg, pck);
@@ -696,14 +699,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
     }
     sg = nsg; c16 = nc16; tap = ntap;
   };
-  static_assert(PD == 2, "the rotation below is written out for three weight sets and two x sets");
-  for (int s = 0; s < a.steps; s += 6) {
+  // the unroll factor is the least common multiple of the PD + 1 weight sets and the two x fragment sets
+  constexpr int UNR = (PD + 1) % 2 == 0 ? PD + 1 : 2 * (PD + 1);
+  static_assert(UNR <= 6, "k_step calls below cover an unroll of up to six");
+  for (int s = 0; s < a.steps; s += UNR) {
     k_step(std::integral_constant<int, 0>{}, s);
     if (s + 1 < a.steps) k_step(std::integral_constant<int, 1>{}, s + 1);
-    if (s + 2 < a.steps) k_step(std::integral_constant<int, 2>{}, s + 2);
-    if (s + 3 < a.steps) k_step(std::integral_constant<int, 3>{}, s + 3);
-    if (s + 4 < a.steps) k_step(std::integral_constant<int, 4>{}, s + 4);
-    if (s + 5 < a.steps) k_step(std::integral_constant<int, 5>{}, s + 5);
+    if (UNR > 2 && s + 2 < a.steps) k_step(std::integral_constant<int, 2 % UNR>{}, s + 2);
+    if (UNR > 3 && s + 3 < a.steps) k_step(std::integral_constant<int, 3 % UNR>{}, s + 3);
+    if (UNR > 4 && s + 4 < a.steps) k_step(std::integral_constant<int, 4 % UNR>{}, s + 4);
+    if (UNR > 5 && s + 5 < a.steps) k_step(std::integral_constant<int, 5 % UNR>{}, s + 5);
   }
   conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
 }
