@@ -75,6 +75,43 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
     float* yb = a.y + (int64_t)b * a.y_bs;
     const float* rb = a.res ? a.res + (int64_t)b * a.res_bs : nullptr;
     const int ycs = (int)a.y_cs, rcs = (int)a.res_cs, tout = (int)a.Tout;
+    // The common case (plain conv, optionally + residual: 5 of 6 vocoder convs, every WaveNet projection) gets a loop
+    // with no per-element flag tests: the general loop below spends more time in uniform branches than in stores.
+    const bool lean = a.act == ACT_NONE && !a.row_scale && a.out_div == 1.f && a.phases == 1 && a.out_tstride == 1 &&
+                      !a.accumulate && a.phase_base == 0;
+    if (lean) {
+      const int tlim = min(tcols, tout);
+      bool colok[NT];
+      bool live[NT];
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni) {
+        colok[ni] = colbase + ni * 32 < tlim;
+        live[ni] = colbase + ni * 32 < olim;
+      }
+#pragma unroll
+      for (int mi = 0; mi < MT; ++mi) {
+        const int mtile = mrow0 + mi * 32;
+        if (mtile >= a.mtiles * 32) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
+          if (co >= a.C) continue;
+          const float bias = a.bias[co];
+          float* yrow = yb + co * ycs + colbase;
+          if (rb) {
+            const float* rrow = rb + co * rcs + colbase;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+              if (colok[ni]) yrow[ni * 32] = live[ni] ? acc[mi][ni][r] + bias + rrow[ni * 32] : 0.f;
+          } else {
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+              if (colok[ni]) yrow[ni * 32] = live[ni] ? acc[mi][ni][r] + bias : 0.f;
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int mtile = mrow0 + mi * 32;
