@@ -81,32 +81,42 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
                       !a.accumulate && a.phase_base == 0;
     if (lean) {
       const int tlim = min(tcols, tout);
-      bool colok[NT];
-      bool live[NT];
+      bool colok[NT], live[NT];
+      int cq[NT];               // column offsets clamped into the row, so residual loads need no predicate
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         colok[ni] = colbase + ni * 32 < tlim;
         live[ni] = colbase + ni * 32 < olim;
+        cq[ni] = min(colbase + ni * 32, tlim - 1);
       }
 #pragma unroll
       for (int mi = 0; mi < MT; ++mi) {
         const int mtile = mrow0 + mi * 32;
         if (mtile >= a.mtiles * 32) continue;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int co = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
-          if (co >= a.C) continue;
-          const float bias = a.bias[co];
-          float* yrow = yb + co * ycs + colbase;
-          if (rb) {
-            const float* rrow = rb + co * rcs + colbase;
+        for (int g = 0; g < 4; ++g) {           // four rows at a time: all their loads are issued before the first use
+          float bias[4], rv[4][NT];
+          int co[4];
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-              if (colok[ni]) yrow[ni * 32] = live[ni] ? acc[mi][ni][r] + bias + rrow[ni * 32] : 0.f;
-          } else {
+          for (int k = 0; k < 4; ++k) {
+            co[k] = mtile + k + 8 * g + 4 * h;
+            const int cc = min(co[k], a.C - 1);
+            bias[k] = a.bias[cc];
+            if (rb) {
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni)
-              if (colok[ni]) yrow[ni * 32] = live[ni] ? acc[mi][ni][r] + bias : 0.f;
+              for (int ni = 0; ni < NT; ++ni) rv[k][ni] = rb[cc * rcs + cq[ni]];
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            if (co[k] >= a.C) continue;
+            float* yrow = yb + co[k] * ycs + colbase;
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+              float v = acc[mi][ni][4 * g + k] + bias[k];
+              if (rb) v += rv[k][ni];
+              if (colok[ni]) yrow[ni * 32] = live[ni] ? v : 0.f;
+            }
           }
         }
       }
@@ -659,35 +669,30 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
   constexpr int PD = DMEL_PD;
   uint4 wa[PD + 1][MT][NP];
 #pragma unroll
-  for (int d = 0; d < PD; ++d)
-    if (d < a.steps) load_w(wa[d], d);
+  for (int d = 0; d < PD; ++d) load_w(wa[d], min(d, a.steps - 1));
   load_x(0, 0);
   store_x(Xb, 0, 0);
   __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0)
   __syncthreads();
   int cstep = 0;                 // K step inside the staged chunk
 
-  // x fragments are double-buffered in registers as well: the ds_reads of step s + 1 are issued in front of the MFMAs of
-  // step s, so inside one wave the MFMAs run back to back (only the first step after a buffer flip waits for LDS).
-  bf16x8 bv[2][NT][NP];
-  auto read_b = [&](bf16x8 (&dst)[NT][NP], int c16_, int tap_) {
-    const uint4* xp = Xb + xbuf * (NP * PSZ) + ((c16_ % SUB) * 2 + h) * XS + wave_n * (NT * 32) + l31 + tap_ * cur_dil;
-#pragma unroll
-    for (int ni = 0; ni < NT; ++ni)
-#pragma unroll
-      for (int p = 0; p < NP; ++p) dst[ni][p] = __builtin_bit_cast(bf16x8, xp[p * PSZ + ni * 32]);
-  };
-  read_b(bv[0], 0, 0);
-
-  // Staging of the NEXT chunk is kept off the barrier's critical path: its global loads are issued at the chunk's first
-  // K step, converted and written into the idle LDS buffer one step later (the buffer was released by the barrier that
-  // opened this chunk), and the barrier that closes the chunk has nothing but MFMAs in front of it.
-  // R = s mod 6 at compile time: weight set R % 3 is consumed and (R + 2) % 3 filled, x fragment set R % 2 consumed.
+  // Wait placement.  The compiler's s_waitcnt insertion is static: where paths with different numbers of loads in flight
+  // merge (steps that also issue the next chunk's x loads vs. steps that do not), it emits the wait that is safe for the
+  // path with the FEWEST younger loads, which on the other paths drains loads issued a few instructions earlier (measured:
+  // a full vmcnt(0) in front of the MFMAs of every chunk's first step).  So the order inside a step is fixed such that one
+  // count is right on all paths:
+  //   top:  issue the weight loads of step s+PD;  read the x fragments of step s from LDS;  MFMAs of step s (their
+  //         weights were waited for at the end of step s-1);
+  //   end:  EXPLICIT vmcnt(#weight loads issued at the top): the weights of step s+1 and any x loads issued at the end of
+  //         step s-1 have landed (both had >= one step of MFMAs);  then the staging work, off the barrier's critical path:
+  //         chunk step 0 issues the next chunk's x loads, chunk step 1 converts them and writes the idle LDS buffer (released
+  //         by the barrier that opened this chunk), so the barrier closing the chunk has only MFMAs in front of it.
+  // (Register double-buffering of the x fragments was tried and dropped: the ds_read latency hides behind the other wave.)
+  constexpr int kWLoads = MT * NP;                                              // weight loads per step and wave
+  constexpr int kWaitW = (kWLoads & 15) | (7 << 4) | (15 << 8) | ((kWLoads >> 4) << 14);   // s_waitcnt vmcnt(kWLoads)
   auto k_step = [&](auto R, int s) {
     constexpr int r = decltype(R)::value;
     uint4 (&use)[MT][NP] = wa[r % (PD + 1)];
-    bf16x8 (&bcur)[NT][NP] = bv[r % 2];
-    bf16x8 (&bnxt)[NT][NP] = bv[(r + 1) % 2];
     int nsg = sg, nc16 = c16, ntap = tap + 1;
     bool newx = false;
     if (ntap == cur_taps) {
@@ -697,32 +702,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
       else newx = (nc16 % SUB) == 0;
     }
     const bool has_next = s + 1 < a.steps;
-    if (s + PD < a.steps) load_w(wa[(r + PD) % (PD + 1)], s + PD);
-    if (cstep == 0) {
-      pending = next_chunk(sg, c16 / SUB, psg, pck);
-      if (pending) load_x(psg, pck);
-    }
-    if (has_next && !newx) read_b(bnxt, nc16, ntap);
-    const bool stage_now = pending && (cstep == 1 || newx);    // second step of the chunk, or its only one
-    if constexpr (NP == 1) {
+    // unconditional (the last PD steps re-fetch the final step's fragments into a set nobody reads again): a branch here
+    // would put a wait-free path into the CFG and with it a conservative vmcnt(0) in front of the MFMAs
+    load_w(wa[(r + PD) % (PD + 1)], min(s + PD, a.steps - 1));
+    {
+      const uint4* xp = Xb + xbuf * (NP * PSZ) + ((c16 % SUB) * 2 + h) * XS + wave_n * (NT * 32) + l31 + tap * cur_dil;
+      bf16x8 bcur[NT][NP];
 #pragma unroll
-      for (int mi = 0; mi < MT; ++mi)
+      for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int ni = 0; ni < NT; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use[mi][0]), bcur[ni][0], acc[mi][ni], 0, 0, 0);
-    } else {
-      // smallest partial products first; the MT*NT independent accumulators separate dependent MFMAs
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};
+        for (int p = 0; p < NP; ++p) bcur[ni][p] = __builtin_bit_cast(bf16x8, xp[p * PSZ + ni * 32]);
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
 #pragma unroll
-      for (int t = 0; t < 6; ++t)
+      for (int t = 0; t < (NP == 3 ? 6 : 1); ++t)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use[mi][PA[t]]), bcur[ni][PB[t]],
-                                                                  acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use[mi][NP == 3 ? PA[t] : 0]),
+                                                                  bcur[ni][NP == 3 ? PB[t] : 0], acc[mi][ni], 0, 0, 0);
     }
-    if (stage_now) {
+    __builtin_amdgcn_s_waitcnt(kWaitW);
+    if (cstep == 0) {
+      pending = next_chunk(sg, c16 / SUB, psg, pck);
+      if (pending) load_x(psg, pck);
+    }
+    if (pending && (cstep == 1 || newx)) {       // second step of the chunk, or its only one
       store_x(Xb + (xbuf ^ 1) * (NP * PSZ), psg, pck);
       pending = false;
     }
@@ -732,12 +737,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
       xbuf ^= 1;
       cstep = 0;
       if (nsg != sg) { cur_taps = a.seg[nsg].taps; cur_nchunk = a.seg[nsg].nchunk; cur_dil = a.seg[nsg].dil; }
-      read_b(bnxt, nc16, ntap);
     }
     sg = nsg; c16 = nc16; tap = ntap;
   };
-  // the unroll factor is the least common multiple of the PD + 1 weight sets and the two x fragment sets
-  constexpr int UNR = (PD + 1) % 2 == 0 ? PD + 1 : 2 * (PD + 1);
+  // unrolled by the PD + 1 weight sets so that they rotate without register copies
+  constexpr int UNR = PD + 1;
   static_assert(UNR <= 6, "k_step calls below cover an unroll of up to six");
   for (int s = 0; s < a.steps; s += UNR) {
     k_step(std::integral_constant<int, 0>{}, s);
