@@ -773,6 +773,8 @@ template <int WM, int WN, int MT, int NT, int MODE, int NP> static int launch_b1
   // 1x1 convolutions stage 32 channels per barrier (two K steps); everything else 16 (taps K steps)
   constexpr int KG0 = (WN * NT * 32 >= 256 && NP == 3) ? 2 : 4;       // keep the widest tile inside 64 KiB of LDS
   if (halo == 0) return launch_b16k<WM, WN, MT, NT, MODE, 0, NP, KG0>(ka, B, mblocks, st);
+  // dilation-1 convs (every second conv of an AMP block, k2 transposed-conv phases): a 16-column halo is enough
+  if (halo <= 16) return launch_b16k<WM, WN, MT, NT, MODE, 16, NP, 2>(ka, B, mblocks, st);
   return launch_b16k<WM, WN, MT, NT, MODE, 64, NP, 2>(ka, B, mblocks, st);
 }
 

@@ -488,7 +488,8 @@ struct dmel_bigvgan {
   // stream are unchanged (everything is ordered behind what was on it and finished when the final join is reached).
   static constexpr int kSide = 2;
   hipStream_t side[kSide] = {nullptr, nullptr};
-  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr}, ev_chain[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr}, ev_chain[3] = {nullptr, nullptr, nullptr},
+             ev_stag[3] = {nullptr, nullptr, nullptr};
   bool multi = false;
   int precision = 0;
   ~dmel_bigvgan() {
@@ -498,6 +499,7 @@ struct dmel_bigvgan {
     }
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     for (auto& e : ev_chain) if (e) (void)hipEventDestroy(e);
+    for (auto& e : ev_stag) if (e) (void)hipEventDestroy(e);
   }
 };
 
@@ -640,6 +642,7 @@ extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
     m->multi = !(e && atoi(e) == 1) && c.num_kernels <= 3 && c.num_kernels > 1;
     DMEL_HIP(hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 3; ++i) DMEL_HIP(hipEventCreateWithFlags(&m->ev_chain[i], hipEventDisableTiming));
+    for (int i = 0; i < 3; ++i) DMEL_HIP(hipEventCreateWithFlags(&m->ev_stag[i], hipEventDisableTiming));
     for (int i = 0; i < dmel_bigvgan::kSide; ++i) {
       DMEL_HIP(hipStreamCreateWithFlags(&m->side[i], hipStreamNonBlocking));
       DMEL_HIP(hipEventCreateWithFlags(&m->ev_join[i], hipEventDisableTiming));
@@ -735,8 +738,13 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
       hipStream_t sj = (multi && j > 0) ? m->side[j - 1] : st;
       float *xj = bufs[3 + 3 * j], *uj = bufs[4 + 3 * j], *vj = bufs[5 + 3 * j];
       const float* xin = xu;
+      static const int stagger = [] { const char* e = getenv("DMEL_BIGVGAN_STAGGER"); return e ? atoi(e) : 1; }();
       for (int l = 0; l < 3; ++l) {
+        // stagger the branches by one kernel: started together they run snake|snake|snake then conv|conv|conv in lockstep
+        // and the VALU-bound activations never meet the matrix-pipe-bound convolutions on a CU
+        if (l == 0 && multi && stagger && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_stag[j - 1], 0));
         DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps, logscale, B, ch, Tc, sj));
+        if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
         ConvRun r1 = run_1seg(uj, ch, Tc, vj, ch, Tc, B);
         r1.precision = m->precision;
     DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
