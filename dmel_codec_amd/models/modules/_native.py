@@ -54,11 +54,13 @@ class NativeModule(nn.Module):
         return self._handle
 
     def set_precision(self, precision) -> None:
-        """"fp32" (default; the parity path) or "bf16": convolution operands rounded to bf16, fp32 accumulation, fp32
-        tensors everywhere else (include/dmel_hip.h, DMEL_PRECISION_*).  Accepts the strings, torch dtypes or 0 / 1."""
-        table = {"fp32": 0, "float32": 0, torch.float32: 0, 0: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1, 1: 1}
+        """"fp32" (default; the parity path), "fp32_mfma" (force the native fp32 MFMA kernel) or "bf16": convolution operands
+        rounded to bf16, fp32 accumulation, fp32 tensors everywhere else (include/dmel_hip.h, DMEL_PRECISION_*).  Accepts the
+        strings, torch dtypes or the DMEL_PRECISION_* integers."""
+        table = {"fp32": 0, "float32": 0, torch.float32: 0, 0: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1, 1: 1,
+                 "fp32_mfma": 2, 2: 2}
         if precision not in table:
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+            raise ValueError(f"precision must be 'fp32', 'fp32_mfma' or 'bf16', got {precision!r}")
         if table[precision] and not self._precision_symbol:
             raise NotImplementedError(f"{type(self).__name__} has no bf16 mode")
         self._precision = table[precision]
