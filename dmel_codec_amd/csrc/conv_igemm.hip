@@ -899,8 +899,9 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     o.Cin = sd.Cin; o.nchunk = (sd.Cin + kCK - 1) / kCK; o.taps = sd.taps; o.dil = sd.dil;
     o.pad_left = sd.pad_left; o.tstride = sd.tstride; o.toff = sd.toff;
     max_halo = std::max(max_halo, (sd.taps - 1) * sd.dil);
-    DMEL_CHECK_ARG((int64_t)sd.Cin * o.cstride < ((int64_t)1 << 31) && o.Tin * sd.tstride < ((int64_t)1 << 30),
-                   "conv: one batch item of the input exceeds 32-bit offsets");
+    // the staging code addresses one batch item with unsigned 32-bit BYTE offsets
+    DMEL_CHECK_ARG((int64_t)sd.Cin * o.cstride < ((int64_t)1 << 30) && o.Tin * sd.tstride < ((int64_t)1 << 30),
+                   "conv: one batch item of the input exceeds 32-bit byte offsets (4 GiB)");
   }
   if (max_halo > 64) {
     set_error("conv_igemm: receptive field (taps-1)*dilation = %d exceeds the 64-sample LDS halo", max_halo);

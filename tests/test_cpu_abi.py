@@ -196,3 +196,25 @@ def test_reference_yaml_instantiates():
                                               load_vocoder_ckpt=False)
     assert len(m.encoder.residual_layers) == 8 and m.quantizer.levels == [8, 6] and m.dmel_groups == 10
     assert m.decoder.condition_channels == 700 and m.encode_mel_transform.n_mels == 100
+
+
+def test_precision_api_validation():
+    """set_precision is host-side state until a handle exists: argument checking needs no GPU."""
+    import pytest
+    from dmel_codec_amd.configs import build_codec
+    codec = build_codec(n_mels=80, dmel_groups=8, encoder_layers=1, decoder_layers=1, vocoder=None)
+    for ok in ("fp32", "bf16", "fp32_mfma", torch.bfloat16, torch.float32, 0, 1, 2):
+        codec.decoder.set_precision(ok)
+    with pytest.raises(ValueError):
+        codec.decoder.set_precision("fp16")
+    with pytest.raises(NotImplementedError):
+        codec.quantizer.set_precision("bf16")          # ids are the interchange format: the quantizer has no bf16 mode
+    codec.quantizer.set_precision("fp32")
+    codec.set_decode_precision("bf16")
+    assert codec.decoder._precision == 1 and codec.encoder._precision == 0
+
+
+def test_precision_entry_points_reject_bad_arguments(L):
+    assert L.dmel_conv_set_precision(None, 0) < 0 and b"PRECISION" in L.dmel_last_error()
+    assert L.dmel_wavenet_set_precision(None, 1) < 0
+    assert L.dmel_bigvgan_set_precision(None, 1) < 0
