@@ -75,6 +75,8 @@ PROTOTYPES = {
     "dmel_conv_create": (C.c_int, [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmel_conv_destroy": (None, [vp]),
     "dmel_conv_set_precision": (C.c_int, [vp, C.c_int]),
+    "dmel_conv_backward_data": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
+    "dmel_conv_backward_weight": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_conv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_prof_enable": (C.c_int, [C.c_int]),
     "dmel_prof_reset": (C.c_int, []),

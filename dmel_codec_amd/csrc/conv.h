@@ -169,3 +169,14 @@ template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, F
 }
 
 }  // namespace dmel
+
+// Single-op handle of the C ABI (dmel_conv_*): forward image, and -- packed on first use -- the transposed, tap-reversed
+// image that turns backward-data into the same convolution kernel.
+struct dmel_conv {
+  dmel::PackedConv pc;
+  int Cout = 0, Cin = 0, k = 0, dil = 0;
+  int precision = 0;
+  std::vector<float> w_host;
+  dmel::PackedConv pc_dgrad;
+  bool dgrad_ready = false;
+};

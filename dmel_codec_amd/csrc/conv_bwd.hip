@@ -1,0 +1,158 @@
+// Backward of the dense 1-D convolution (first piece of SURVEY.md section 8(f) rank 1: the training path).
+//
+// The reference has no hand-written backward: `loss.backward()` runs ATen's conv1d double-backward kernels through autograd
+// (codec_lit_modules.py:236,315 -> torch/nn/functional conv1d).  For y = conv1d(x, W, b, dilation d, "same" padding p):
+//   dx[ci, t]      = sum_{co, k} W[co, ci, K-1-k] * dy[co, t + k*d - p]         backward-data: the SAME convolution with the
+//                                                                               weights transposed and tap-reversed
+//   dW[co, ci, k]  = sum_{b, t} dy[b, co, t] * x[b, ci, t + k*d - p]            backward-weight: a GEMM over (b, t)
+//   db[co]         = sum_{b, t} dy[b, co, t]
+// backward-data therefore reuses conv_igemm.hip unchanged (fp32-grade, the forward kernel's tiles and rates).
+// backward-weight is its own kernel below: per tap a (Cout x Cin) GEMM whose reduction runs over batch x time, on the fp32
+// MFMA (exact fp32 products; gradients are summed over ~10^5 samples, so accumulation order is the only noise), split over
+// K across workgroups with fp32 atomics.
+#include "conv.h"
+
+namespace dmel {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWgTile = 64;     // workgroup tile: 64 output channels x 64 input channels of one tap
+constexpr int kWgK = 64;        // time samples staged per step
+constexpr int kWgPitch = 66;    // LDS row pitch in floats: bank = 2*row + col -> fragment reads and staging writes conflict-free
+
+struct WgArgs {
+  const float* dy;
+  const float* x;
+  float* dw;
+  int Cout, Cin, taps, dil, pad, B, T;
+  int chunks_per_item, slices, chunks_per_slice;
+};
+
+// grid (ceil(Cin/64), ceil(Cout/64), taps * slices); 256 threads = 2 x 2 waves of 32 x 32
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
+  __shared__ float dys[kWgTile * kWgPitch];
+  __shared__ float xs[kWgTile * kWgPitch];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ci0 = blockIdx.x * kWgTile, co0 = blockIdx.y * kWgTile;
+  const int tap = blockIdx.z % a.taps, slice = blockIdx.z / a.taps;
+  const int shift = tap * a.dil - a.pad;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const int total = a.B * a.chunks_per_item;
+  const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
+  const int r31 = lane & 31, h = lane >> 5;
+  for (int c = c_begin; c < c_end; ++c) {
+    const int b = c / a.chunks_per_item, t0 = (c - b * a.chunks_per_item) * kWgK;
+    const float* dyb = a.dy + (int64_t)b * a.Cout * a.T;
+    const float* xb = a.x + (int64_t)b * a.Cin * a.T;
+    // stage dy[co0 .. co0+63][t0 .. t0+63] and x[ci0 .. ci0+63][t0+shift ..]: one 256-byte row segment per wave and pass
+    float vd[16], vx[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = wave + 4 * i;
+      const int t = t0 + lane, tx = t + shift;
+      const int co = co0 + row, ci = ci0 + row;
+      const bool okd = co < a.Cout && t < a.T, okx = ci < a.Cin && t < a.T && tx >= 0 && tx < a.T;
+      const float d = dyb[(int64_t)min(co, a.Cout - 1) * a.T + min(t, a.T - 1)];
+      const float v = xb[(int64_t)min(ci, a.Cin - 1) * a.T + min(max(tx, 0), a.T - 1)];
+      vd[i] = okd ? d : 0.f;
+      vx[i] = okx ? v : 0.f;
+    }
+    __syncthreads();      // the previous step's fragment reads are done
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = wave + 4 * i;
+      dys[row * kWgPitch + lane] = vd[i];
+      xs[row * kWgPitch + lane] = vx[i];
+    }
+    __syncthreads();
+    const float* ap = dys + (wm * 32 + r31) * kWgPitch + h;
+    const float* bp = xs + (wn * 32 + r31) * kWgPitch + h;
+#pragma unroll
+    for (int j = 0; j < kWgK / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * j], bp[2 * j], acc, 0, 0, 0);
+  }
+  // D[row = co][col = ci]: acc[r] <-> row (r & 3) + 8 * (r >> 2) + 4 * h, col = lane & 31
+  const int ci = ci0 + wn * 32 + r31;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+      if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps + tap, acc[r]);
+    }
+  }
+}
+
+// db[co] = sum over (b, t): one workgroup per output channel
+__global__ __launch_bounds__(256) void conv_bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int Cout, int B, int T) {
+  __shared__ float part[4];
+  const int co = blockIdx.x;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float* row = dy + ((int64_t)b * Cout + co) * T;
+    for (int t = threadIdx.x; t < T; t += 256) s += row[t];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) db[co] = part[0] + part[1] + part[2] + part[3];
+}
+
+}  // namespace dmel
+
+using namespace dmel;
+
+extern "C" int dmel_conv_backward_data(dmel_conv* c, const float* dy, float* dx, int B, int64_t T, void* stream) {
+  DMEL_CHECK_ARG(c && dy && dx, "conv_backward_data: NULL argument");
+  DMEL_CHECK_ARG(B > 0 && T > 0, "conv_backward_data: bad shape");
+  if (!c->dgrad_ready) {
+    DMEL_CHECK_ARG(!c->w_host.empty(), "conv_backward_data: handle holds no host weights");
+    PackDesc d;
+    d.mode = EPI_LINEAR; d.nseg = 1; d.C = c->Cin; d.phases = 1;
+    d.seg[0].Cin = c->Cout; d.seg[0].taps = c->k; d.seg[0].dil = c->dil; d.seg[0].pad_left = c->dil * (c->k - 1) / 2;
+    const int Cin = c->Cin, K = c->k;
+    const float* w = c->w_host.data();
+    DMEL_TRY(pack_conv(c->pc_dgrad, d,
+                       [&](int, int row /*ci*/, int cc /*co*/, int tap) { return w[((size_t)cc * Cin + row) * K + (K - 1 - tap)]; },
+                       [&](int) { return 0.f; }));
+    c->dgrad_ready = true;
+  }
+  ConvRun r;
+  r.seg[0].x = dy; r.seg[0].bstride = (int64_t)c->Cout * T; r.seg[0].cstride = T; r.seg[0].Tin = T;
+  r.B = B; r.Tcols = T; r.y = dx; r.y_bs = (int64_t)c->Cin * T; r.y_cs = T; r.Tout = T;
+  r.precision = c->precision == DMEL_PRECISION_BF16 ? DMEL_PRECISION_FP32 : c->precision;     // gradients stay fp32-grade
+  return launch_conv(c->pc_dgrad, r, (hipStream_t)stream);
+}
+
+extern "C" int dmel_conv_backward_weight(const dmel_conv* c, const float* x, const float* dy, float* dw, float* db, int B,
+                                         int64_t T, void* stream) {
+  DMEL_CHECK_ARG(c && x && dy && dw, "conv_backward_weight: NULL argument");
+  DMEL_CHECK_ARG(B > 0 && T > 0 && T < ((int64_t)1 << 30), "conv_backward_weight: bad shape");
+  hipStream_t st = (hipStream_t)stream;
+  WgArgs a;
+  a.dy = dy; a.x = x; a.dw = dw;
+  a.Cout = c->Cout; a.Cin = c->Cin; a.taps = c->k; a.dil = c->dil; a.pad = c->dil * (c->k - 1) / 2; a.B = B; a.T = (int)T;
+  a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
+  const int tiles = ((c->Cin + kWgTile - 1) / kWgTile) * ((c->Cout + kWgTile - 1) / kWgTile) * c->k;
+  const int total = B * a.chunks_per_item;
+  // enough K slices to fill the chip (~8 workgroups per CU), each at least 8 staged steps long
+  int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
+  slices = std::min(slices, 65535 / std::max(1, c->k));
+  a.slices = slices;
+  a.chunks_per_slice = (total + slices - 1) / slices;
+  DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)c->Cout * c->Cin * c->k * sizeof(float), st));
+  dim3 grid((unsigned)((c->Cin + kWgTile - 1) / kWgTile), (unsigned)((c->Cout + kWgTile - 1) / kWgTile), (unsigned)(c->k * slices));
+  {
+    ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * c->Cout * c->Cin * c->k, 0.0);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, a);
+  }
+  DMEL_HIP(hipGetLastError());
+  if (db) {
+    hipLaunchKernelGGL(conv_bgrad_kernel, dim3((unsigned)c->Cout), dim3(256), 0, st, dy, db, c->Cout, B, (int)T);
+    DMEL_HIP(hipGetLastError());
+  }
+  return DMEL_OK;
+}

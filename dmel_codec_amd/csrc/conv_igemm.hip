@@ -940,11 +940,6 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
 using namespace dmel;
 
 // ---- single-op C ABI (tests / module mirrors) ---------------------------------------------------
-struct dmel_conv {
-  PackedConv pc;
-  int Cout, Cin, k, dil;
-  int precision = 0;
-};
 
 extern "C" int dmel_conv_set_precision(dmel_conv* c, int precision) {
   DMEL_CHECK_ARG(c && valid_precision(precision), "conv_set_precision: not a DMEL_PRECISION_* value");
@@ -965,6 +960,7 @@ extern "C" int dmel_conv_create(dmel_conv** out, const float* w_host, const floa
                      [&](int, int row, int ci, int tap) { return w_host[((size_t)row * Cin + ci) * k + tap]; },
                      [&](int row) { return bias_host ? bias_host[row] : 0.f; });
   if (rc != DMEL_OK) { delete c; return rc; }
+  c->w_host.assign(w_host, w_host + (size_t)Cout * Cin * k);      // kept for the lazily packed backward-data weights
   *out = c;
   return DMEL_OK;
 }

@@ -174,6 +174,15 @@ int dmel_conv_create(dmel_conv** c, const float* w_host, const float* bias_host 
 void dmel_conv_destroy(dmel_conv* c);
 int dmel_conv_set_precision(dmel_conv* c, int precision);
 int dmel_conv_forward(const dmel_conv* c, const float* x, float* y, int B, int64_t T, void* stream);
+/* Backward of the same convolution -- what autograd runs for the reference (`loss.backward()`, codec_lit_modules.py:236,315 ->
+ * ATen conv1d backward); first piece of the training path (SURVEY.md section 8(f) rank 1, C-ABI row `conv1d_dilated(+_bwd)`).
+ *   backward_data:   dx (B, Cin, T)  = conv1d(dy, W transposed and tap-reversed)   -- the forward kernel on a second weight image
+ *   backward_weight: dw (Cout, Cin, k) = sum_{b,t} dy[b,co,t] * x[b,ci,t + k*d - p], db (Cout) = sum_{b,t} dy   (db nullable)
+ * dw / db are overwritten.  The K split of backward_weight uses fp32 atomics: results are reproducible to rounding, not
+ * bitwise.  Gradients are always fp32-grade (a BF16 handle falls back to FP32 here). */
+int dmel_conv_backward_data(dmel_conv* c, const float* dy, float* dx, int B, int64_t T, void* stream);
+int dmel_conv_backward_weight(const dmel_conv* c, const float* x, const float* dy, float* dw, float* db /*nullable*/, int B,
+                              int64_t T, void* stream);
 
 /* Timing hook used by bench.py: when enabled, every launch of the named kernel family on `stream` is
  * bracketed by hipEvents; dmel_prof_read returns the launch count and total milliseconds since the last reset

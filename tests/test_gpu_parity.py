@@ -592,3 +592,42 @@ def test_split_fp32_conv_is_fp32_grade(dev, Cout, Cin, k, dil, T, B):
         assert errs["split"] < 1.5 * errs["native"] + 1e-7, errs
     finally:
         L.dmel_conv_destroy(h)
+
+
+# ------------------------------------------------------------------------------------ conv backward (training path, first piece)
+@pytest.mark.parametrize("Cout,Cin,k,dil,T,B", [
+    (32, 32, 3, 1, 100, 2), (64, 48, 7, 3, 257, 2), (140, 70, 3, 4, 93, 5), (70, 140, 1, 1, 93, 5), (128, 128, 11, 5, 700, 1),
+    (33, 17, 5, 2, 65, 3), (1120, 560, 3, 2, 92, 2), (100, 560, 1, 1, 92, 3),
+])
+def test_conv_backward_matches_autograd(dev, Cout, Cin, k, dil, T, B):
+    """dmel_conv_backward_data / _weight against torch autograd of F.conv1d evaluated in float64 (what the reference's
+    loss.backward() computes for every ConvNorm / Conv1d of the WaveNets, codec_lit_modules.py:236,315)."""
+    from dmel_codec_amd import _lib
+    torch.manual_seed(Cout + 7 * Cin + k + T)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    b = torch.randn(Cout) * 0.1
+    x = torch.randn(B, Cin, T)
+    dy = torch.randn(B, Cout, T)
+    w64, b64, x64 = w.double().requires_grad_(), b.double().requires_grad_(), x.double().requires_grad_()
+    F.conv1d(x64, w64, b64, dilation=dil, padding=dil * (k - 1) // 2).backward(dy.double())
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), b.data_ptr(), Cout, Cin, k, dil))
+    try:
+        xd, dyd = x.to(dev), dy.to(dev)
+        dx = torch.empty(B, Cin, T, device=dev)
+        dw = torch.full((Cout, Cin, k), float("nan"), device=dev)        # must be overwritten, not accumulated into
+        db = torch.full((Cout,), float("nan"), device=dev)
+        st = _lib.stream_ptr()
+        _lib.check(L.dmel_conv_backward_data(h, dyd.data_ptr(), dx.data_ptr(), B, T, st))
+        _lib.check(L.dmel_conv_backward_weight(h, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), B, T, st))
+        torch.cuda.synchronize()
+        assert rel_err(dx, x64.grad) < 2e-6
+        assert rel_err(dw, w64.grad) < 2e-6
+        assert rel_err(db, b64.grad) < 2e-6
+        _lib.check(L.dmel_conv_backward_weight(h, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), None, B, T, st))   # db optional
+        torch.cuda.synchronize()
+        assert rel_err(dw, w64.grad) < 2e-6
+        assert L.dmel_conv_backward_data(h, None, dx.data_ptr(), B, T, st) < 0
+    finally:
+        L.dmel_conv_destroy(h)
