@@ -10,7 +10,7 @@
 // backward-weight is its own kernel below: per tap a (Cout x Cin) GEMM whose reduction runs over batch x time, on the fp32
 // MFMA (exact fp32 products; gradients are summed over ~10^5 samples, so accumulation order is the only noise), split over
 // K across workgroups with fp32 atomics.
-#include "conv.h"
+#include "ops.h"
 
 namespace dmel {
 
@@ -101,6 +101,35 @@ __global__ __launch_bounds__(256) void conv_bgrad_kernel(const float* __restrict
   if (threadIdx.x == 0) db[co] = part[0] + part[1] + part[2] + part[3];
 }
 
+int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int Cout, int Cin, int taps, int dil, int B, int64_t T,
+                      hipStream_t st) {
+  DMEL_CHECK_ARG(x && dy && dw, "conv_wgrad: NULL argument");
+  DMEL_CHECK_ARG(B > 0 && T > 0 && T < ((int64_t)1 << 30) && Cout > 0 && Cin > 0 && taps > 0 && dil > 0, "conv_wgrad: bad shape");
+  WgArgs a;
+  a.dy = dy; a.x = x; a.dw = dw;
+  a.Cout = Cout; a.Cin = Cin; a.taps = taps; a.dil = dil; a.pad = dil * (taps - 1) / 2; a.B = B; a.T = (int)T;
+  a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
+  const int tiles = ((Cin + kWgTile - 1) / kWgTile) * ((Cout + kWgTile - 1) / kWgTile) * taps;
+  const int total = B * a.chunks_per_item;
+  // enough K slices to fill the chip (~8 workgroups per CU), each at least 8 staged steps long
+  int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
+  slices = std::min(slices, 65535 / std::max(1, taps));
+  a.slices = slices;
+  a.chunks_per_slice = (total + slices - 1) / slices;
+  DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * taps * sizeof(float), st));
+  dim3 grid((unsigned)((Cin + kWgTile - 1) / kWgTile), (unsigned)((Cout + kWgTile - 1) / kWgTile), (unsigned)(taps * slices));
+  {
+    ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Cout * Cin * taps, 0.0);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, a);
+  }
+  DMEL_HIP(hipGetLastError());
+  if (db) {
+    hipLaunchKernelGGL(conv_bgrad_kernel, dim3((unsigned)Cout), dim3(256), 0, st, dy, db, Cout, B, (int)T);
+    DMEL_HIP(hipGetLastError());
+  }
+  return DMEL_OK;
+}
+
 }  // namespace dmel
 
 using namespace dmel;
@@ -130,29 +159,5 @@ extern "C" int dmel_conv_backward_data(dmel_conv* c, const float* dy, float* dx,
 extern "C" int dmel_conv_backward_weight(const dmel_conv* c, const float* x, const float* dy, float* dw, float* db, int B,
                                          int64_t T, void* stream) {
   DMEL_CHECK_ARG(c && x && dy && dw, "conv_backward_weight: NULL argument");
-  DMEL_CHECK_ARG(B > 0 && T > 0 && T < ((int64_t)1 << 30), "conv_backward_weight: bad shape");
-  hipStream_t st = (hipStream_t)stream;
-  WgArgs a;
-  a.dy = dy; a.x = x; a.dw = dw;
-  a.Cout = c->Cout; a.Cin = c->Cin; a.taps = c->k; a.dil = c->dil; a.pad = c->dil * (c->k - 1) / 2; a.B = B; a.T = (int)T;
-  a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
-  const int tiles = ((c->Cin + kWgTile - 1) / kWgTile) * ((c->Cout + kWgTile - 1) / kWgTile) * c->k;
-  const int total = B * a.chunks_per_item;
-  // enough K slices to fill the chip (~8 workgroups per CU), each at least 8 staged steps long
-  int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
-  slices = std::min(slices, 65535 / std::max(1, c->k));
-  a.slices = slices;
-  a.chunks_per_slice = (total + slices - 1) / slices;
-  DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)c->Cout * c->Cin * c->k * sizeof(float), st));
-  dim3 grid((unsigned)((c->Cin + kWgTile - 1) / kWgTile), (unsigned)((c->Cout + kWgTile - 1) / kWgTile), (unsigned)(c->k * slices));
-  {
-    ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * c->Cout * c->Cin * c->k, 0.0);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, a);
-  }
-  DMEL_HIP(hipGetLastError());
-  if (db) {
-    hipLaunchKernelGGL(conv_bgrad_kernel, dim3((unsigned)c->Cout), dim3(256), 0, st, dy, db, c->Cout, B, (int)T);
-    DMEL_HIP(hipGetLastError());
-  }
-  return DMEL_OK;
+  return launch_conv_wgrad(x, dy, dw, db, c->Cout, c->Cin, c->k, c->dil, B, T, (hipStream_t)stream);
 }

@@ -93,6 +93,15 @@ struct dmel_wavenet {
   PackedConv in_proj, skip_proj, out_proj;
   std::vector<PackedConv> gate, resskip;
   int precision = 0;
+  // training path (enable_training before finalize): unfused forward images that expose the gate pre-activations, and the
+  // transposed images that turn every backward-data into a forward convolution
+  bool train = false, train_ready = false;
+  struct TrainLayer { PackedConv pre_lin, out_lin, pre_dx, pre_dc, out_dz; int dil = 1; };
+  std::vector<TrainLayer> tl;
+  PackedConv in_dx, skip_dx, out_dx;
+  struct GradSlot { std::string key; int64_t offset, numel; };
+  std::vector<GradSlot> slots;
+  int64_t grad_floats = 0;
 };
 
 
@@ -133,6 +142,99 @@ static int pack_pointwise(PackedConv& pc, const TensorStore& ts, const std::stri
                    [&](int row) { return b->v[row]; });
 }
 
+// transposed 1x1: y (rows = Cin of the forward conv) = W^T applied to a (Cout-channel) gradient; no bias
+static int pack_pointwise_T(PackedConv& pc, const HostTensor* w, int Cout, int Cin) {
+  PackDesc d;
+  d.mode = EPI_LINEAR; d.nseg = 1; d.C = Cin; d.seg[0].Cin = Cout;
+  return pack_conv(pc, d, [&](int, int row, int cc, int) { return w->v[(size_t)cc * Cin + row]; }, [&](int) { return 0.f; });
+}
+
+static int wavenet_pack_training(dmel_wavenet* m) {
+  const int C = m->C, Cc = m->Ccond;
+  m->tl.clear();
+  m->tl.resize(m->L);
+  m->slots.clear();
+  int64_t off = 0;
+  auto slot = [&](const std::string& key, int64_t numel) { m->slots.push_back({key, off, numel}); off += numel; };
+  if (m->has_in) {
+    const HostTensor* w = m->ts.need("input_projection.conv.weight", {C, m->Cin, 1});
+    if (!w) return DMEL_EMISSING;
+    DMEL_TRY(pack_pointwise_T(m->in_dx, w, C, m->Cin));
+    slot("input_projection.conv.weight", (int64_t)C * m->Cin);
+    slot("input_projection.conv.bias", C);
+  }
+  for (int i = 0; i < m->L; ++i) {
+    const std::string p = "residual_layers." + std::to_string(i) + ".";
+    const int dil = m->cycle ? 1 << (i % m->cycle) : 1;
+    dmel_wavenet::TrainLayer& t = m->tl[i];
+    t.dil = dil;
+    const HostTensor* cw = m->ts.need(p + "conv_layer.conv.weight", {2 * C, C, 3});
+    const HostTensor* cb = m->ts.need(p + "conv_layer.conv.bias", {2 * C});
+    const HostTensor* ow = m->ts.need(p + "output_projection.conv.weight", {2 * C, C, 1});
+    const HostTensor* ob = m->ts.need(p + "output_projection.conv.bias", {2 * C});
+    if (!cw || !cb || !ow || !ob) return DMEL_EMISSING;
+    const HostTensor *qw = nullptr, *qb = nullptr;
+    if (Cc) {
+      qw = m->ts.need(p + "condition_projection.conv.weight", {2 * C, Cc, 1});
+      qb = m->ts.need(p + "condition_projection.conv.bias", {2 * C});
+      if (!qw || !qb) return DMEL_EMISSING;
+    }
+    PackDesc d;      // pre-activation of the gate, rows in their natural order (wavenet.py:121-127)
+    d.mode = EPI_LINEAR; d.C = 2 * C; d.nseg = Cc ? 2 : 1;
+    d.seg[0].Cin = C; d.seg[0].taps = 3; d.seg[0].dil = dil; d.seg[0].pad_left = dil;
+    d.seg[1].Cin = Cc;
+    DMEL_TRY(pack_conv(t.pre_lin, d,
+                       [&](int sg, int row, int ci, int tap) {
+                         return sg == 0 ? cw->v[((size_t)row * C + ci) * 3 + tap] : qw->v[(size_t)row * Cc + ci];
+                       },
+                       [&](int row) { return cb->v[row] + (qb ? qb->v[row] : 0.f); }));
+    PackDesc e;
+    e.mode = EPI_LINEAR; e.C = 2 * C; e.nseg = 1; e.seg[0].Cin = C;
+    DMEL_TRY(pack_conv(t.out_lin, e, [&](int, int row, int ci, int) { return ow->v[(size_t)row * C + ci]; },
+                       [&](int row) { return ob->v[row]; }));
+    PackDesc g;      // d pre -> d x: transposed, tap-reversed dilated conv
+    g.mode = EPI_LINEAR; g.C = C; g.nseg = 1;
+    g.seg[0].Cin = 2 * C; g.seg[0].taps = 3; g.seg[0].dil = dil; g.seg[0].pad_left = dil;
+    DMEL_TRY(pack_conv(t.pre_dx, g, [&](int, int row, int cc, int tap) { return cw->v[((size_t)cc * C + row) * 3 + (2 - tap)]; },
+                       [&](int) { return 0.f; }));
+    if (Cc) DMEL_TRY(pack_pointwise_T(t.pre_dc, qw, 2 * C, Cc));
+    DMEL_TRY(pack_pointwise_T(t.out_dz, ow, 2 * C, C));
+    slot(p + "conv_layer.conv.weight", (int64_t)2 * C * C * 3);
+    slot(p + "conv_layer.conv.bias", 2 * C);
+    if (Cc) {
+      slot(p + "condition_projection.conv.weight", (int64_t)2 * C * Cc);
+      slot(p + "condition_projection.conv.bias", 2 * C);
+    }
+    slot(p + "output_projection.conv.weight", (int64_t)2 * C * C);
+    slot(p + "output_projection.conv.bias", 2 * C);
+  }
+  {
+    const HostTensor* w = m->ts.need("skip_projection.conv.weight", {C, C, 1});
+    if (!w) return DMEL_EMISSING;
+    DMEL_TRY(pack_pointwise_T(m->skip_dx, w, C, C));
+    slot("skip_projection.conv.weight", (int64_t)C * C);
+    slot("skip_projection.conv.bias", C);
+  }
+  if (m->has_out) {
+    const HostTensor* w = m->ts.need("output_projection.conv.weight", {m->Cout, C, 1});
+    if (!w) return DMEL_EMISSING;
+    DMEL_TRY(pack_pointwise_T(m->out_dx, w, m->Cout, C));
+    slot("output_projection.conv.weight", (int64_t)m->Cout * C);
+    slot("output_projection.conv.bias", m->Cout);
+  }
+  m->grad_floats = off;
+  m->train_ready = true;
+  return DMEL_OK;
+}
+
+extern "C" int dmel_wavenet_enable_training(dmel_wavenet* m, int on) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  m->train = on != 0;
+  m->ready = false;          // takes effect at the next finalize (the host tensors are needed)
+  m->train_ready = false;
+  return DMEL_OK;
+}
+
 extern "C" int dmel_wavenet_finalize(dmel_wavenet* m) {
   DMEL_CHECK_ARG(m, "NULL handle");
   const int C = m->C;
@@ -170,6 +272,7 @@ extern "C" int dmel_wavenet_finalize(dmel_wavenet* m) {
   }
   DMEL_TRY(pack_pointwise(m->skip_proj, m->ts, "skip_projection.conv.", C, C));
   if (m->has_out) DMEL_TRY(pack_pointwise(m->out_proj, m->ts, "output_projection.conv.", m->Cout, C));
+  if (m->train) DMEL_TRY(wavenet_pack_training(m));
   m->ts.t.clear();
   m->ready = true;
   return DMEL_OK;
@@ -237,6 +340,196 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
       o.precision = m->precision;
     DMEL_TRY(launch_conv(m->out_proj, o, st));
     }
+  }
+  return DMEL_OK;
+}
+
+// ---- WaveNet training path --------------------------------------------------------------------------------------
+// forward_train computes exactly wavenet.py:204-225 but unfused, keeping what backward needs (every block's input, gate
+// pre-activation and gated output; the SiLU inputs); backward is reverse-mode differentiation of that graph -- what
+// `manual_backward(loss)` (codec_lit_modules.py:236,315) does through autograd -- built from: backward-data = the forward
+// conv kernel on transposed weights, backward-weight = conv_wgrad_kernel, and the elementwise kernels of train_ops.hip.
+namespace {
+struct TrainPlan {
+  float *X, *PRE, *Z, *U, *XS, *P, *Q, *SK, *O;          // saved by forward (X: L+1 slabs, PRE: L x 2n, Z: L slabs)
+  float *GXa, *GXb, *GS, *GO, *GXS, *DZ, *DPRE, *DP, *DQ;   // backward temporaries
+  size_t n, bytes;
+};
+TrainPlan train_plan(const dmel_wavenet* m, int N, int64_t T, void* ws) {
+  TrainPlan p{};
+  Arena a(ws, (size_t)-1);
+  const size_t n = (size_t)N * m->C * T;
+  p.n = n;
+  p.X = a.take<float>(n * (m->L + 1));
+  p.PRE = a.take<float>(2 * n * m->L);
+  p.Z = a.take<float>(n * m->L);
+  p.U = m->has_in ? a.take<float>(n) : nullptr;
+  p.XS = a.take<float>(n);
+  p.P = a.take<float>(n);
+  p.Q = m->has_out ? a.take<float>(n) : nullptr;
+  p.SK = a.take<float>(n);
+  p.O = a.take<float>(2 * n);
+  p.GXa = a.take<float>(n);
+  p.GXb = a.take<float>(n);
+  p.GS = a.take<float>(n);
+  p.GO = a.take<float>(2 * n);
+  p.GXS = a.take<float>(n);
+  p.DZ = a.take<float>(n);
+  p.DPRE = a.take<float>(2 * n);
+  p.DP = a.take<float>(n);
+  p.DQ = m->has_out ? a.take<float>(n) : nullptr;
+  p.bytes = align_up(a.off, 256);
+  return p;
+}
+int train_precision(const dmel_wavenet* m) { return m->precision == DMEL_PRECISION_BF16 ? DMEL_PRECISION_FP32 : m->precision; }
+}  // namespace
+
+extern "C" size_t dmel_wavenet_train_workspace_bytes(const dmel_wavenet* m, int N, int64_t T) {
+  if (!m || N <= 0 || T <= 0) return 0;
+  return train_plan(m, N, T, nullptr).bytes;
+}
+extern "C" int64_t dmel_wavenet_grad_floats(const dmel_wavenet* m) { return m && m->train_ready ? m->grad_floats : 0; }
+extern "C" int dmel_wavenet_grad_slot(const dmel_wavenet* m, const char* key, int64_t* offset, int64_t* numel) {
+  DMEL_CHECK_ARG(m && key && offset && numel, "wavenet_grad_slot: NULL argument");
+  if (!m->train_ready) { set_error("wavenet_grad_slot: training was not enabled before finalize"); return DMEL_EMISSING; }
+  for (const auto& s : m->slots)
+    if (s.key == key) { *offset = s.offset; *numel = s.numel; return DMEL_OK; }
+  set_error("wavenet_grad_slot: '%s' is not a trained parameter of this WaveNet", key);
+  return DMEL_EINVAL;
+}
+
+extern "C" int dmel_wavenet_forward_train(const dmel_wavenet* m, const float* x, const float* condition, float* y, int N, int64_t T,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(m && x && y && workspace, "wavenet_forward_train: NULL argument");
+  if (!m->ready || !m->train_ready) { set_error("wavenet_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG((m->Ccond != 0) == (condition != nullptr), "wavenet_forward_train: condition tensor does not match the configuration");
+  DMEL_CHECK_ARG(N > 0 && T > 0, "wavenet_forward_train: bad shape");
+  const TrainPlan p = train_plan(m, N, T, workspace);
+  DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "wavenet_forward_train: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = m->C, prec = train_precision(m);
+  const size_t n = p.n;
+  if (m->has_in) {  // wavenet.py:205-207
+    ConvRun r = run_1seg(x, m->Cin, T, p.U, C, T, N);
+    r.precision = prec;
+    DMEL_TRY(launch_conv(m->in_proj, r, st));
+    DMEL_TRY(launch_silu_fwd(p.U, p.X, (int64_t)n, st));
+  } else {
+    DMEL_HIP(hipMemcpyAsync(p.X, x, n * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  for (int i = 0; i < m->L; ++i) {  // wavenet.py:116-135
+    const float* xi = p.X + (size_t)i * n;
+    float* pre = p.PRE + (size_t)i * 2 * n;
+    float* z = p.Z + (size_t)i * n;
+    ConvRun g = run_1seg(xi, C, T, pre, 2 * C, T, N);
+    if (m->Ccond) { g.seg[1].x = condition; g.seg[1].bstride = (int64_t)m->Ccond * T; g.seg[1].cstride = T; g.seg[1].Tin = T; }
+    g.precision = prec;
+    DMEL_TRY(launch_conv(m->tl[i].pre_lin, g, st));
+    DMEL_TRY(launch_gate_fwd(pre, z, N, C, T, st));
+    ConvRun o = run_1seg(z, C, T, p.O, 2 * C, T, N);
+    o.precision = prec;
+    DMEL_TRY(launch_conv(m->tl[i].out_lin, o, st));
+    DMEL_TRY(launch_resskip_fwd(xi, p.O, p.X + (size_t)(i + 1) * n, p.SK, i == 0, N, C, T, st));
+  }
+  DMEL_TRY(launch_scale(p.SK, p.XS, (float)(1.0 / std::sqrt((double)m->L)), (int64_t)n, st));   // wavenet.py:218
+  {
+    ConvRun r = run_1seg(p.XS, C, T, m->has_out ? p.P : y, C, T, N);
+    r.precision = prec;
+    DMEL_TRY(launch_conv(m->skip_proj, r, st));
+  }
+  if (m->has_out) {  // wavenet.py:221-223
+    DMEL_TRY(launch_silu_fwd(p.P, p.Q, (int64_t)n, st));
+    ConvRun o = run_1seg(p.Q, C, T, y, m->Cout, T, N);
+    o.precision = prec;
+    DMEL_TRY(launch_conv(m->out_proj, o, st));
+  }
+  return DMEL_OK;
+}
+
+extern "C" int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, const float* condition, const float* dy, float* dx,
+                                     float* dcondition, float* grads, int N, int64_t T, void* workspace, size_t workspace_bytes,
+                                     void* stream) {
+  DMEL_CHECK_ARG(m && x && dy && grads && workspace, "wavenet_backward: NULL argument");
+  if (!m->ready || !m->train_ready) { set_error("wavenet_backward: enable_training + finalize first"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG((m->Ccond != 0) == (condition != nullptr), "wavenet_backward: condition tensor does not match the configuration");
+  DMEL_CHECK_ARG(N > 0 && T > 0, "wavenet_backward: bad shape");
+  const TrainPlan p = train_plan(m, N, T, workspace);
+  DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "wavenet_backward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = m->C, Cc = m->Ccond, prec = train_precision(m);
+  const size_t n = p.n;
+  auto G = [&](const std::string& key) -> float* {
+    for (const auto& s : m->slots)
+      if (s.key == key) return grads + s.offset;
+    return nullptr;
+  };
+  // ---- tail: y = out_proj(silu(P)), P = skip_proj(XS), XS = SK / sqrt(L) ----
+  const float* dP = dy;
+  if (m->has_out) {
+    DMEL_TRY(launch_conv_wgrad(p.Q, dy, G("output_projection.conv.weight"), G("output_projection.conv.bias"), m->Cout, C, 1, 1, N, T, st));
+    ConvRun r = run_1seg(dy, m->Cout, T, p.DQ, C, T, N);
+    r.precision = prec;
+    DMEL_TRY(launch_conv(m->out_dx, r, st));
+    DMEL_TRY(launch_silu_bwd(p.DQ, p.P, p.DP, (int64_t)n, st));
+    dP = p.DP;
+  }
+  DMEL_TRY(launch_conv_wgrad(p.XS, dP, G("skip_projection.conv.weight"), G("skip_projection.conv.bias"), C, C, 1, 1, N, T, st));
+  {
+    ConvRun r = run_1seg(dP, C, T, p.DZ, C, T, N);      // DZ as scratch: d XS
+    r.precision = prec;
+    DMEL_TRY(launch_conv(m->skip_dx, r, st));
+    DMEL_TRY(launch_scale(p.DZ, p.GS, (float)(1.0 / std::sqrt((double)m->L)), (int64_t)n, st));   // d skip of every block
+  }
+  // ---- blocks in reverse; gx = d loss / d x_{i+1}; x_L feeds nothing but the (discarded) last residual: gx starts at 0 ----
+  float* gx = p.GXa;
+  float* gx_prev = p.GXb;
+  DMEL_HIP(hipMemsetAsync(gx, 0, n * sizeof(float), st));
+  for (int i = m->L - 1; i >= 0; --i) {
+    const std::string pk = "residual_layers." + std::to_string(i) + ".";
+    const dmel_wavenet::TrainLayer& t = m->tl[i];
+    const float* xi = p.X + (size_t)i * n;
+    const float* pre = p.PRE + (size_t)i * 2 * n;
+    const float* z = p.Z + (size_t)i * n;
+    DMEL_TRY(launch_resskip_bwd(gx, p.GS, p.GO, p.GXS, N, C, T, st));
+    DMEL_TRY(launch_conv_wgrad(z, p.GO, G(pk + "output_projection.conv.weight"), G(pk + "output_projection.conv.bias"), 2 * C, C, 1, 1, N,
+                               T, st));
+    {
+      ConvRun r = run_1seg(p.GO, 2 * C, T, p.DZ, C, T, N);
+      r.precision = prec;
+      DMEL_TRY(launch_conv(t.out_dz, r, st));
+    }
+    DMEL_TRY(launch_gate_bwd(p.DZ, pre, p.DPRE, N, C, T, st));
+    float* db = G(pk + "conv_layer.conv.bias");
+    DMEL_TRY(launch_conv_wgrad(xi, p.DPRE, G(pk + "conv_layer.conv.weight"), db, 2 * C, C, 3, t.dil, N, T, st));
+    if (Cc) {
+      DMEL_TRY(launch_conv_wgrad(condition, p.DPRE, G(pk + "condition_projection.conv.weight"), nullptr, 2 * C, Cc, 1, 1, N, T, st));
+      DMEL_HIP(hipMemcpyAsync(G(pk + "condition_projection.conv.bias"), db, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+      if (dcondition) {
+        ConvRun r = run_1seg(p.DPRE, 2 * C, T, dcondition, Cc, T, N);
+        r.accumulate = (i != m->L - 1);
+        r.precision = prec;
+        DMEL_TRY(launch_conv(t.pre_dc, r, st));
+      }
+    }
+    {
+      ConvRun r = run_1seg(p.DPRE, 2 * C, T, gx_prev, C, T, N);     // d x_i = gx / sqrt2 + W^T d pre
+      r.res = p.GXS; r.res_bs = (int64_t)C * T; r.res_cs = T;
+      r.precision = prec;
+      DMEL_TRY(launch_conv(t.pre_dx, r, st));
+    }
+    std::swap(gx, gx_prev);
+  }
+  // ---- head: x_0 = silu(U), U = in_proj(x) ----
+  if (m->has_in) {
+    DMEL_TRY(launch_silu_bwd(gx, p.U, p.DP, (int64_t)n, st));
+    DMEL_TRY(launch_conv_wgrad(x, p.DP, G("input_projection.conv.weight"), G("input_projection.conv.bias"), C, m->Cin, 1, 1, N, T, st));
+    if (dx) {
+      ConvRun r = run_1seg(p.DP, C, T, dx, m->Cin, T, N);
+      r.precision = prec;
+      DMEL_TRY(launch_conv(m->in_dx, r, st));
+    }
+  } else if (dx) {
+    DMEL_HIP(hipMemcpyAsync(dx, gx, n * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   return DMEL_OK;
 }

@@ -25,4 +25,17 @@ int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, in
 int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host, int logscale,
                     int B, int C, int64_t T, hipStream_t s);
 
+
+// ---- training path (train_ops.hip, conv_bwd.hip) --------------------------------------------------------------
+int launch_gate_fwd(const float* pre, float* z, int N, int C, int64_t T, hipStream_t s);
+int launch_gate_bwd(const float* dz, const float* pre, float* dpre, int N, int C, int64_t T, hipStream_t s);
+int launch_resskip_fwd(const float* x, const float* o, float* xn, float* skipsum, int first, int N, int C, int64_t T, hipStream_t s);
+int launch_resskip_bwd(const float* gx, const float* gs, float* go, float* gxs, int N, int C, int64_t T, hipStream_t s);
+int launch_silu_fwd(const float* u, float* y, int64_t total, hipStream_t s);
+int launch_silu_bwd(const float* g, const float* u, float* du, int64_t total, hipStream_t s);
+int launch_scale(const float* x, float* y, float k, int64_t total, hipStream_t s);
+// dw (Cout, Cin, taps) = sum_{b,t} dy[b,co,t] * x[b,ci,t + k*dil - pad], pad = dil*(taps-1)/2; db (Cout) nullable.  Overwrites.
+int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int Cout, int Cin, int taps, int dil, int B, int64_t T,
+                      hipStream_t s);
+
 }  // namespace dmel

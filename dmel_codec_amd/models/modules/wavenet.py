@@ -1,7 +1,9 @@
 """WaveNet on the MI355X.  Drop-in for dmel_codec/models/modules/wavenet.py (reference): same class names, ctor
 kwargs, parameter names (state-dict keys) and initialisation; forward runs the fused HIP path
 (csrc/modules.hip: dmel_wavenet_forward) -- one implicit-GEMM launch per gated conv and one per output projection.
-Inference only (no autograd through the native call)."""
+When gradients are required (grad mode on and a parameter or input requires grad) forward runs the native training path
+instead (dmel_wavenet_forward_train / dmel_wavenet_backward behind a torch.autograd.Function): the same arithmetic unfused,
+with hand-written backward kernels -- what the reference gets from autograd (codec_lit_modules.py:236,315)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -51,6 +53,55 @@ class ResidualBlock(nn.Module):
             self.diffusion_projection = LinearNorm(residual_channels, residual_channels, use_linear_bias)
             self.condition_projection = ConvNorm(condition_channels, 2 * residual_channels, kernel_size=1)
         self.output_projection = ConvNorm(residual_channels, 2 * residual_channels, kernel_size=1)
+
+
+class _WaveNetTrainFn(torch.autograd.Function):
+    """Native forward-with-saved-activations / backward of the whole WaveNet (include/dmel_hip.h, training path)."""
+
+    @staticmethod
+    def forward(ctx, module, x, condition, *params):
+        L = _lib.lib()
+        N, _, T = x.shape
+        dev = x.device
+        y = torch.empty(N, module.output_channels, T, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            h = module.native()
+            ws = torch.empty(L.dmel_wavenet_train_workspace_bytes(h, N, T), dtype=torch.uint8, device=dev)
+            _lib.check(L.dmel_wavenet_forward_train(h, x.data_ptr(), _lib.ptr(condition), y.data_ptr(), N, T, ws.data_ptr(),
+                                                    ws.numel(), _lib.stream_ptr()), "wavenet_forward_train")
+        ctx.module, ctx.handle, ctx.ws = module, h, ws
+        ctx.save_for_backward(x, condition if condition is not None else torch.empty(0, device=dev))
+        ctx.has_cond = condition is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        module, h, ws = ctx.module, ctx.handle, ctx.ws
+        x, cond = ctx.saved_tensors
+        cond = cond if ctx.has_cond else None
+        if module._handle != h:
+            raise RuntimeError("WaveNet parameters changed between forward and backward")
+        L = _lib.lib()
+        N, _, T = x.shape
+        dev = x.device
+        dy = dy.float().contiguous()
+        need_dx, need_dc = ctx.needs_input_grad[1], ctx.has_cond and ctx.needs_input_grad[2]
+        dx = torch.empty_like(x) if need_dx else None
+        dc = torch.empty_like(cond) if need_dc else None
+        with torch.cuda.device(dev):
+            flat = torch.empty(L.dmel_wavenet_grad_floats(h), dtype=torch.float32, device=dev)
+            _lib.check(L.dmel_wavenet_backward(h, x.data_ptr(), _lib.ptr(cond), dy.data_ptr(), _lib.ptr(dx), _lib.ptr(dc),
+                                               flat.data_ptr(), N, T, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+                       "wavenet_backward")
+        grads = []
+        off, num = C.c_int64(), C.c_int64()
+        for (key, prm), need in zip(module._trained_parameters(), ctx.needs_input_grad[3:]):
+            if not need:
+                grads.append(None)
+                continue
+            _lib.check(L.dmel_wavenet_grad_slot(h, key.encode(), C.byref(off), C.byref(num)), "wavenet_grad_slot")
+            grads.append(flat[off.value:off.value + num.value].view(prm.shape))
+        return (None, dx, dc, *grads)
 
 
 class WaveNet(NativeModule):
@@ -104,10 +155,54 @@ class WaveNet(NativeModule):
                                                   self.residual_channels, len(self.residual_layers),
                                                   self.dilation_cycle or 0, self.condition_channels or 0),
                    "wavenet_create")
+        if getattr(self, "_want_train", False):
+            _lib.check(_lib.lib().dmel_wavenet_enable_training(h, 1), "wavenet_enable_training")
         return h.value
 
-    @torch.no_grad()
+    def _trained_parameters(self):
+        """(state-dict key, parameter) of everything the native backward produces a gradient for, in a fixed order
+        (the dead diffusion_projection weights receive none, as in the reference)."""
+        return [(k, p) for k, p in self.named_parameters() if "diffusion_projection" not in k]
+
     def forward(self, x, t=None, condition=None, in_lengths=None, out_lengths=None, group_repeat: int = 1):
+        if torch.is_grad_enabled() and (x.requires_grad or (condition is not None and condition.requires_grad)
+                                        or any(p.requires_grad for _, p in self._trained_parameters())):
+            return self._forward_train(x, t, condition, in_lengths, out_lengths, group_repeat)
+        with torch.no_grad():
+            return self._forward_infer(x, t, condition, in_lengths, out_lengths, group_repeat)
+
+    def _forward_train(self, x, t, condition, in_lengths, out_lengths, group_repeat):
+        """Differentiable forward: masks (if given) are applied as plain tensor ops around the native call, exactly where
+        the reference multiplies them (codec_lit_modules.py:189-190, 205-211)."""
+        if t is not None:
+            raise NotImplementedError("diffusion step input is not built (never used by the codec path)")
+        _lib.require_cuda(x, "x")
+        if x.ndim != 3 or x.shape[1] != self.input_channels:
+            raise ValueError(f"expected (N, {self.input_channels}, T), got {tuple(x.shape)}")
+        if (condition is not None) != bool(self.condition_channels):
+            raise ValueError("condition tensor does not match condition_channels")
+        N, _, T = x.shape
+
+        def mask(v):
+            v = v.reshape(-1).to(device=x.device, dtype=torch.int64)
+            if v.numel() * group_repeat != N:
+                raise ValueError("lengths do not match the batch")
+            m = (torch.arange(T, device=x.device)[None, :] < v[:, None]).to(torch.float32)
+            return m.repeat_interleave(group_repeat, dim=0)[:, None, :]
+
+        x = x.float()
+        if in_lengths is not None:
+            x = x * mask(in_lengths)
+        if not getattr(self, "_want_train", False):
+            self._want_train = True
+            self._free_native()              # the training images are packed at finalize: rebuild the handle once
+        params = [p for _, p in self._trained_parameters()]
+        y = _WaveNetTrainFn.apply(self, x.contiguous(), condition.float().contiguous() if condition is not None else None, *params)
+        if out_lengths is not None:
+            y = y * mask(out_lengths)
+        return y
+
+    def _forward_infer(self, x, t=None, condition=None, in_lengths=None, out_lengths=None, group_repeat: int = 1):
         """x (N, Cin, T), condition (N, Ccond, T) -> (N, Cout, T).
         Extensions (optional): in_lengths / out_lengths (N // group_repeat,) int64 fuse the `x * mask` in front of
         and behind the stack (codec_lit_modules.py:471-477, 505-506)."""

@@ -110,6 +110,24 @@ int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const float* con
                          const int64_t* in_lengths, const int64_t* out_lengths, int group_repeat,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Training path of the WaveNet (first module of SURVEY.md section 8(f) rank 1; C-ABI row `wavenet_block(+_bwd)`): what
+ * `manual_backward(loss)` differentiates through autograd in the reference (codec_lit_modules.py:236,315 over
+ * wavenet.py:116-135,204-225).  enable_training must precede finalize (the transposed weight images are packed there).
+ * forward_train = forward without masks, keeping in `workspace` what backward needs; backward must be given the SAME
+ * workspace, untouched, plus x / condition again.  Parameter gradients are written (overwritten) into one flat fp32 device
+ * buffer of dmel_wavenet_grad_floats() elements; dmel_wavenet_grad_slot maps a state-dict key to its (offset, numel) there
+ * (layout of each slot = the parameter's own layout).  dx / dcondition may be NULL when not needed.  Gradients are
+ * fp32-grade regardless of the handle's precision. */
+int dmel_wavenet_enable_training(dmel_wavenet* m, int on);
+size_t dmel_wavenet_train_workspace_bytes(const dmel_wavenet* m, int N, int64_t T);
+int64_t dmel_wavenet_grad_floats(const dmel_wavenet* m);
+int dmel_wavenet_grad_slot(const dmel_wavenet* m, const char* key, int64_t* offset, int64_t* numel);
+int dmel_wavenet_forward_train(const dmel_wavenet* m, const float* x, const float* condition, float* y, int N, int64_t T,
+                               void* workspace, size_t workspace_bytes, void* stream);
+int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, const float* condition, const float* dy, float* dx /*nullable*/,
+                          float* dcondition /*nullable*/, float* grads, int N, int64_t T, void* workspace, size_t workspace_bytes,
+                          void* stream);
+
 /* DownsampleFiniteScalarQuantize (is_dmel=True, n_codebooks=1)   replaces models/modules/dowmsample_fsq.py:124-147
  * and vector_quantize_pytorch GroupedResidualFSQ.forward / get_output_from_indices. */
 typedef struct dmel_quantizer dmel_quantizer;

@@ -631,3 +631,66 @@ def test_conv_backward_matches_autograd(dev, Cout, Cin, k, dil, T, B):
         assert L.dmel_conv_backward_data(h, None, dx.data_ptr(), B, T, st) < 0
     finally:
         L.dmel_conv_destroy(h)
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(input_channels=10, residual_channels=70, residual_layers=5, dilation_cycle=4, N=6, T=93),                     # encoder-like
+    dict(input_channels=48, output_channels=20, residual_channels=48, residual_layers=4, dilation_cycle=4,
+         condition_channels=48, N=3, T=61),                                                                               # decoder-like
+    dict(residual_channels=64, residual_layers=3, dilation_cycle=2, N=2, T=130),                                         # no projections
+    dict(input_channels=560, output_channels=80, residual_channels=560, residual_layers=2, dilation_cycle=4,
+         condition_channels=560, N=2, T=92),                                                                              # real decoder widths
+])
+def test_wavenet_training_forward_backward(dev, cfg):
+    """Native forward_train / backward of the WaveNet against autograd through the oracle in float64: output, input and
+    condition gradients and the gradient of every parameter (what manual_backward produces in training_step,
+    codec_lit_modules.py:236,315).  Also: forward_train == inference forward, and the dead diffusion weights get no grad."""
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    cfg = dict(cfg)
+    N, T = cfg.pop("N"), cfg.pop("T")
+    torch.manual_seed(T + N)
+    m = WaveNet(**cfg)
+    randomise(m, 40 + N)
+    sd = cpu_sd(m)
+    sd64 = {k: v.double().requires_grad_() for k, v in sd.items()}
+    cin = m.input_channels
+    x = torch.randn(N, cin, T)
+    cond = torch.randn(N, cfg["condition_channels"], T) if cfg.get("condition_channels") else None
+    gy = torch.randn(N, m.output_channels, T)
+    x64 = x.double().requires_grad_()
+    c64 = cond.double().requires_grad_() if cond is not None else None
+    y64 = ref_cpu.wavenet_forward(sd64, "", x64, len(m.residual_layers), m.dilation_cycle or 0, c64)
+    (y64 * gy.double()).sum().backward()
+
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_()
+    cd = cond.to(dev).requires_grad_() if cond is not None else None
+    y = m(xd, condition=cd)
+    assert y.requires_grad
+    with torch.no_grad():
+        y_inf = m(xd.detach(), condition=cd.detach() if cd is not None else None)
+    assert rel_err(y, y64) < 2e-5 and rel_err(y_inf, y64) < 2e-5
+    (y * gy.to(dev)).sum().backward()
+    assert rel_err(xd.grad, x64.grad) < 2e-5
+    if cond is not None:
+        assert rel_err(cd.grad, c64.grad) < 2e-5
+    checked = 0
+    for k, p in m.named_parameters():
+        if "diffusion_projection" in k:
+            assert p.grad is None
+            continue
+        assert p.grad is not None, k
+        assert rel_err(p.grad, sd64[k].grad) < 2e-5, (k, rel_err(p.grad, sd64[k].grad))
+        checked += 1
+    assert checked == len([k for k in sd if "diffusion_projection" not in k])
+    # a second step after an optimiser-style in-place update rebuilds the handle and still matches
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.01 * torch.randn_like(p))
+    m.zero_grad()
+    y2 = m(xd.detach(), condition=cd.detach() if cd is not None else None)
+    sd2 = {k: v.double() for k, v in cpu_sd(m).items()}
+    assert rel_err(y2, ref_cpu.wavenet_forward(sd2, "", x.double(), len(m.residual_layers), m.dilation_cycle or 0,
+                                               cond.double() if cond is not None else None)) < 2e-5
+    y2.sum().backward()
+    assert m.skip_projection.conv.weight.grad is not None
