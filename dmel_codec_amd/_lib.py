@@ -53,6 +53,7 @@ PROTOTYPES = {
     "dmel_wavenet_destroy": (None, [vp]),
     "dmel_wavenet_set_precision": (C.c_int, [vp, C.c_int]),
     "dmel_wavenet_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_wavenet_refresh": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), vp]),
     "dmel_wavenet_train_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_wavenet_grad_floats": (C.c_int64, [vp]),
     "dmel_wavenet_grad_slot": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -36,6 +36,22 @@ struct PackedConv {
   DevBuf w48;              // the same weights as three exact bf16 pieces (truncation split), same order (split-fp32 kernel)
 };
 
+// Device-side re-pack (training: the weights change every optimiser step and live on the device).  A segment's source is an
+// affine view of a device tensor: value(src_row, ci, tap) = w[src_row*rs + ci*cs + (rev ? taps-1-tap : tap)*ts]; the bias of
+// a source row is b0[row] (+ b1[row]), or 0.  launch_repack rewrites pc.w / pc.w16 / pc.w48 / pc.bias in place from such
+// views, producing bit-identical images to pack_conv on the same values (tests hold it to that).
+struct RepackSeg {
+  const float* w = nullptr;
+  int64_t rs = 0, cs = 0, ts = 0;
+  int rev = 0;
+};
+struct RepackSrc {
+  RepackSeg seg[2];
+  const float* b0 = nullptr;
+  const float* b1 = nullptr;
+};
+int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t stream);
+
 // get_w(seg, src_row, ci, tap) returns the source weight; get_b(src_row) the bias (0 if none).
 // Source row numbering: LINEAR: phase*C + co ; paired: kind*C + c.
 template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, FW get_w, FB get_b);

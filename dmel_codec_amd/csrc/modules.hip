@@ -99,6 +99,16 @@ struct dmel_wavenet {
   struct TrainLayer { PackedConv pre_lin, out_lin, pre_dx, pre_dc, out_dz; int dil = 1; };
   std::vector<TrainLayer> tl;
   PackedConv in_dx, skip_dx, out_dx;
+  // how every weight image derives from the state-dict tensors, for the device-side re-pack after an optimiser step
+  struct Recipe {
+    PackedConv* pc;
+    struct Seg { std::string key; int64_t rs, cs, ts; int rev; } seg[2];
+    std::string b0, b1;
+  };
+  std::vector<Recipe> recipes;
+  void recipe(PackedConv* pc, Recipe::Seg s0, Recipe::Seg s1 = {"", 0, 0, 0, 0}, std::string b0 = "", std::string b1 = "") {
+    recipes.push_back({pc, {s0, s1}, b0, b1});
+  }
   struct GradSlot { std::string key; int64_t offset, numel; };
   std::vector<GradSlot> slots;
   int64_t grad_floats = 0;
@@ -160,6 +170,7 @@ static int wavenet_pack_training(dmel_wavenet* m) {
     const HostTensor* w = m->ts.need("input_projection.conv.weight", {C, m->Cin, 1});
     if (!w) return DMEL_EMISSING;
     DMEL_TRY(pack_pointwise_T(m->in_dx, w, C, m->Cin));
+    m->recipe(&m->in_dx, {"input_projection.conv.weight", 1, m->Cin, 0, 0});
     slot("input_projection.conv.weight", (int64_t)C * m->Cin);
     slot("input_projection.conv.bias", C);
   }
@@ -199,6 +210,13 @@ static int wavenet_pack_training(dmel_wavenet* m) {
                        [&](int) { return 0.f; }));
     if (Cc) DMEL_TRY(pack_pointwise_T(t.pre_dc, qw, 2 * C, Cc));
     DMEL_TRY(pack_pointwise_T(t.out_dz, ow, 2 * C, C));
+    m->recipe(&t.pre_lin, {p + "conv_layer.conv.weight", 3 * C, 3, 1, 0},
+              Cc ? dmel_wavenet::Recipe::Seg{p + "condition_projection.conv.weight", Cc, 1, 0, 0} : dmel_wavenet::Recipe::Seg{"", 0, 0, 0, 0},
+              p + "conv_layer.conv.bias", Cc ? p + "condition_projection.conv.bias" : "");
+    m->recipe(&t.out_lin, {p + "output_projection.conv.weight", C, 1, 0, 0}, {"", 0, 0, 0, 0}, p + "output_projection.conv.bias");
+    m->recipe(&t.pre_dx, {p + "conv_layer.conv.weight", 3, 3 * C, 1, 1});
+    if (Cc) m->recipe(&t.pre_dc, {p + "condition_projection.conv.weight", 1, Cc, 0, 0});
+    m->recipe(&t.out_dz, {p + "output_projection.conv.weight", 1, C, 0, 0});
     slot(p + "conv_layer.conv.weight", (int64_t)2 * C * C * 3);
     slot(p + "conv_layer.conv.bias", 2 * C);
     if (Cc) {
@@ -212,6 +230,7 @@ static int wavenet_pack_training(dmel_wavenet* m) {
     const HostTensor* w = m->ts.need("skip_projection.conv.weight", {C, C, 1});
     if (!w) return DMEL_EMISSING;
     DMEL_TRY(pack_pointwise_T(m->skip_dx, w, C, C));
+    m->recipe(&m->skip_dx, {"skip_projection.conv.weight", 1, C, 0, 0});
     slot("skip_projection.conv.weight", (int64_t)C * C);
     slot("skip_projection.conv.bias", C);
   }
@@ -219,6 +238,7 @@ static int wavenet_pack_training(dmel_wavenet* m) {
     const HostTensor* w = m->ts.need("output_projection.conv.weight", {m->Cout, C, 1});
     if (!w) return DMEL_EMISSING;
     DMEL_TRY(pack_pointwise_T(m->out_dx, w, m->Cout, C));
+    m->recipe(&m->out_dx, {"output_projection.conv.weight", 1, C, 0, 0});
     slot("output_projection.conv.weight", (int64_t)m->Cout * C);
     slot("output_projection.conv.bias", m->Cout);
   }
@@ -238,7 +258,11 @@ extern "C" int dmel_wavenet_enable_training(dmel_wavenet* m, int on) {
 extern "C" int dmel_wavenet_finalize(dmel_wavenet* m) {
   DMEL_CHECK_ARG(m, "NULL handle");
   const int C = m->C;
-  if (m->has_in) DMEL_TRY(pack_pointwise(m->in_proj, m->ts, "input_projection.conv.", C, m->Cin));
+  m->recipes.clear();
+  if (m->has_in) {
+    DMEL_TRY(pack_pointwise(m->in_proj, m->ts, "input_projection.conv.", C, m->Cin));
+    m->recipe(&m->in_proj, {"input_projection.conv.weight", m->Cin, 1, 0, 0}, {"", 0, 0, 0, 0}, "input_projection.conv.bias");
+  }
   m->gate.clear(); m->resskip.clear();
   m->gate.resize(m->L); m->resskip.resize(m->L);
   for (int i = 0; i < m->L; ++i) {
@@ -269,9 +293,17 @@ extern "C" int dmel_wavenet_finalize(dmel_wavenet* m) {
     e.mode = EPI_RESSKIP; e.C = C; e.nseg = 1; e.seg[0].Cin = C;
     DMEL_TRY(pack_conv(m->resskip[i], e, [&](int, int row, int ci, int) { return ow->v[(size_t)row * C + ci]; },
                        [&](int row) { return ob->v[row]; }));
+    m->recipe(&m->gate[i], {p + "conv_layer.conv.weight", 3 * C, 3, 1, 0},
+              Cc ? dmel_wavenet::Recipe::Seg{p + "condition_projection.conv.weight", Cc, 1, 0, 0} : dmel_wavenet::Recipe::Seg{"", 0, 0, 0, 0},
+              p + "conv_layer.conv.bias", Cc ? p + "condition_projection.conv.bias" : "");
+    m->recipe(&m->resskip[i], {p + "output_projection.conv.weight", C, 1, 0, 0}, {"", 0, 0, 0, 0}, p + "output_projection.conv.bias");
   }
   DMEL_TRY(pack_pointwise(m->skip_proj, m->ts, "skip_projection.conv.", C, C));
-  if (m->has_out) DMEL_TRY(pack_pointwise(m->out_proj, m->ts, "output_projection.conv.", m->Cout, C));
+  m->recipe(&m->skip_proj, {"skip_projection.conv.weight", C, 1, 0, 0}, {"", 0, 0, 0, 0}, "skip_projection.conv.bias");
+  if (m->has_out) {
+    DMEL_TRY(pack_pointwise(m->out_proj, m->ts, "output_projection.conv.", m->Cout, C));
+    m->recipe(&m->out_proj, {"output_projection.conv.weight", C, 1, 0, 0}, {"", 0, 0, 0, 0}, "output_projection.conv.bias");
+  }
   if (m->train) DMEL_TRY(wavenet_pack_training(m));
   m->ts.t.clear();
   m->ready = true;
@@ -383,6 +415,35 @@ TrainPlan train_plan(const dmel_wavenet* m, int N, int64_t T, void* ws) {
 }
 int train_precision(const dmel_wavenet* m) { return m->precision == DMEL_PRECISION_BF16 ? DMEL_PRECISION_FP32 : m->precision; }
 }  // namespace
+
+extern "C" int dmel_wavenet_refresh(dmel_wavenet* m, int n, const char* const* keys, const float* const* device_tensors,
+                                    void* stream) {
+  DMEL_CHECK_ARG(m && keys && device_tensors && n > 0, "wavenet_refresh: bad argument");
+  if (!m->ready) { set_error("wavenet_refresh: handle not finalized"); return DMEL_EMISSING; }
+  std::map<std::string, const float*> dev;
+  for (int i = 0; i < n; ++i) {
+    DMEL_CHECK_ARG(keys[i] && device_tensors[i], "wavenet_refresh: NULL entry %d", i);
+    dev[keys[i]] = device_tensors[i];
+  }
+  auto find = [&](const std::string& k, const float** out) -> int {
+    if (k.empty()) { *out = nullptr; return DMEL_OK; }
+    auto it = dev.find(k);
+    if (it == dev.end()) { set_error("wavenet_refresh: tensor '%s' was not provided", k.c_str()); return DMEL_EMISSING; }
+    *out = it->second;
+    return DMEL_OK;
+  };
+  for (auto& r : m->recipes) {
+    RepackSrc src;
+    for (int sgi = 0; sgi < 2; ++sgi) {
+      DMEL_TRY(find(r.seg[sgi].key, &src.seg[sgi].w));
+      src.seg[sgi].rs = r.seg[sgi].rs; src.seg[sgi].cs = r.seg[sgi].cs; src.seg[sgi].ts = r.seg[sgi].ts; src.seg[sgi].rev = r.seg[sgi].rev;
+    }
+    DMEL_TRY(find(r.b0, &src.b0));
+    DMEL_TRY(find(r.b1, &src.b1));
+    DMEL_TRY(launch_repack(*r.pc, src, (hipStream_t)stream));
+  }
+  return DMEL_OK;
+}
 
 extern "C" size_t dmel_wavenet_train_workspace_bytes(const dmel_wavenet* m, int N, int64_t T) {
   if (!m || N <= 0 || T <= 0) return 0;

@@ -76,6 +76,96 @@ unsigned blocks_for(int64_t total) { return (unsigned)std::min<int64_t>((total +
 
 }  // namespace
 
+// ---- device-side weight re-pack: one thread per (packed row m, K step, k in 0..15) element ------------------------------
+struct RepackArgs {
+  RepackSeg seg[2];
+  const float* b0;
+  const float* b1;
+  float* w;
+  uint16_t* w16;
+  uint16_t* w48;
+  float* bias;
+  int mode, C, RP, phases, nseg, Mpad, steps;
+  int Cin[2], taps[2], nchunk[2];
+};
+
+__device__ __forceinline__ int repack_src_row(const RepackArgs& a, int m) {      // conv.h: pack_conv::src_row
+  if (a.mode != EPI_LINEAR) {
+    const int q32 = m >> 5, rho = m & 31, grp = rho >> 3, i = rho & 7;
+    const int c = q32 * 16 + (grp >> 1) * 8 + i;
+    return c >= a.C ? -1 : (grp & 1) * a.C + c;
+  }
+  if (m >= a.RP * a.phases) return -1;
+  const int ph = m / a.RP, co = m % a.RP;
+  return co >= a.C ? -1 : ph * a.C + co;
+}
+
+__global__ void repack_kernel(RepackArgs a) {
+  const int64_t total = (int64_t)a.Mpad * a.steps * kCK;
+  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(e % kCK);
+    const int step = (int)((e / kCK) % a.steps);
+    const int m = (int)(e / ((int64_t)kCK * a.steps));
+    int sg = 0, ls = step;
+    if (a.nseg > 1 && ls >= a.nchunk[0] * a.taps[0]) { ls -= a.nchunk[0] * a.taps[0]; sg = 1; }
+    const int ch = ls / a.taps[sg], tp = ls - ch * a.taps[sg];
+    const int ci = ch * kCK + k;
+    const int sr = repack_src_row(a, m);
+    float v = 0.f;
+    if (sr >= 0 && ci < a.Cin[sg]) {
+      const RepackSeg& s = a.seg[sg];
+      const int t = s.rev ? a.taps[sg] - 1 - tp : tp;
+      v = s.w[sr * s.rs + ci * s.cs + t * s.ts];
+    }
+    const int tile = m >> 5, r = m & 31;
+    {  // fp32 image: [tile][step][half][lane][4], lane = 32*(k&1) + r
+      const int h = k & 1, kk = k >> 1, hf = kk >> 2, j = kk & 3, lane = 32 * h + r;
+      a.w[((((int64_t)tile * a.steps + step) * 2 + hf) * 64 + lane) * 4 + j] = v;
+    }
+    {  // bf16 images: [tile][step][(piece)][lane][8], lane = 32*(k>>3) + r
+      const int h = k >> 3, j = k & 7, lane = 32 * h + r;
+      const uint32_t u = __float_as_uint(v);
+      uint16_t rne;
+      if ((u & 0x7fffffffu) > 0x7f800000u) rne = (uint16_t)((u >> 16) | 0x40);
+      else rne = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+      a.w16[(((int64_t)tile * a.steps + step) * 64 + lane) * 8 + j] = rne;
+      const float p1 = __uint_as_float(u & 0xffff0000u), r1 = v - p1;
+      const float p2 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u), r2 = r1 - p2;
+      const int64_t base = ((int64_t)tile * a.steps + step) * 3;
+      a.w48[((base + 0) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(p1) >> 16);
+      a.w48[((base + 1) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(p2) >> 16);
+      a.w48[((base + 2) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(r2) >> 16);
+    }
+    if (step == 0 && k == 0) {
+      float b = 0.f;
+      if (sr >= 0) {
+        if (a.b0) b = a.b0[sr];
+        if (a.b1) b += a.b1[sr];
+      }
+      a.bias[m] = b;
+    }
+  }
+}
+
+int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t s) {
+  const PackDesc& d = pc.d;
+  DMEL_CHECK_ARG(pc.w.p && pc.w16.p && pc.w48.p && pc.bias.p, "repack: the convolution was never packed");
+  DMEL_CHECK_ARG(d.nseg >= 1 && d.nseg <= 2 && src.seg[0].w && (d.nseg == 1 || src.seg[1].w), "repack: missing source tensor");
+  RepackArgs a{};
+  a.seg[0] = src.seg[0]; a.seg[1] = src.seg[1];
+  a.b0 = src.b0; a.b1 = src.b1;
+  a.w = pc.w.as<float>(); a.w16 = pc.w16.as<uint16_t>(); a.w48 = pc.w48.as<uint16_t>(); a.bias = pc.bias.as<float>();
+  a.mode = d.mode; a.C = d.C; a.RP = pc.RP; a.phases = d.phases; a.nseg = d.nseg; a.Mpad = pc.Mpad; a.steps = pc.steps;
+  for (int i = 0; i < d.nseg; ++i) {
+    a.Cin[i] = d.seg[i].Cin; a.taps[i] = d.seg[i].taps; a.nchunk[i] = (d.seg[i].Cin + kCK - 1) / kCK;
+  }
+  if (d.nseg == 1) { a.Cin[1] = 0; a.taps[1] = 1; a.nchunk[1] = 0; }
+  const int64_t total = (int64_t)pc.Mpad * pc.steps * kCK;
+  hipLaunchKernelGGL(repack_kernel, dim3(blocks_for(total)), dim3(256), 0, s, a);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
 #define DMEL_EW_LAUNCH(kernel, total, bytes_per_elem, ...)                                  \
   do {                                                                                      \
     ProfScope ps("train_elementwise", s, 0.0, (double)(bytes_per_elem) * (double)(total));  \

@@ -119,6 +119,10 @@ int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const float* con
  * (layout of each slot = the parameter's own layout).  dx / dcondition may be NULL when not needed.  Gradients are
  * fp32-grade regardless of the handle's precision. */
 int dmel_wavenet_enable_training(dmel_wavenet* m, int on);
+/* Re-pack every weight image of a finalized handle from DEVICE tensors (after an optimiser step): keys / device_tensors
+ * name the state-dict tensors (weights (Cout, Cin, k) and biases, contiguous fp32) as they currently live on the device.
+ * Runs on `stream`, no host copy, no allocation; produces bit-identical images to set_tensor + finalize on the same values. */
+int dmel_wavenet_refresh(dmel_wavenet* m, int n, const char* const* keys, const float* const* device_tensors, void* stream);
 size_t dmel_wavenet_train_workspace_bytes(const dmel_wavenet* m, int N, int64_t T);
 int64_t dmel_wavenet_grad_floats(const dmel_wavenet* m);
 int dmel_wavenet_grad_slot(const dmel_wavenet* m, const char* key, int64_t* offset, int64_t* numel);

@@ -694,3 +694,19 @@ def test_wavenet_training_forward_backward(dev, cfg):
                                                cond.double() if cond is not None else None)) < 2e-5
     y2.sum().backward()
     assert m.skip_projection.conv.weight.grad is not None
+    # ... and that update went through the device-side re-pack (same handle), whose images are bit-identical to a rebuild
+    h_before = m._handle
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.01)
+        y3 = m(xd.detach(), condition=cd.detach() if cd is not None else None)
+        assert m._handle == h_before
+        m._free_native()
+        y4 = m(xd.detach(), condition=cd.detach() if cd is not None else None)
+        assert m._handle is not None and torch.equal(y3, y4)
+    g3 = torch.autograd.grad(m(xd.detach(), condition=cd.detach() if cd is not None else None).sum(), m.skip_projection.conv.weight)[0]
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(1.0)                    # version bump, same values: refresh path again
+    g4 = torch.autograd.grad(m(xd.detach(), condition=cd.detach() if cd is not None else None).sum(), m.skip_projection.conv.weight)[0]
+    assert rel_err(g4, g3) < 1e-6          # (wgrad uses atomics: equal to rounding, not bitwise)
