@@ -49,6 +49,7 @@ PROTOTYPES = {
     "dmel_stft_num_frames": (C.c_int64, [vp, C.c_int64]),
     "dmel_stft_logmel_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_aa_snake_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    "dmel_aa_snake_backward_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_wavenet_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmel_wavenet_destroy": (None, [vp]),
     "dmel_wavenet_set_precision": (C.c_int, [vp, C.c_int]),

@@ -121,6 +121,125 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__
   else aa_snake_tile<true>(xr, yr, tp, a, inv_b, t0, len, T, xs, vs, threadIdx.x);
 }
 
+// ---- backward ------------------------------------------------------------------------------------------------------
+// The reference has no backward for its fused kernel (alias_free_activation/cuda/activation1d.py:29-32 raises
+// NotImplementedError; training goes through the six-op torch path and autograd).  Reverse mode of the forward above:
+//   dv[i]   = sum_{t,k : clamp(2t+k-5) = i} f[k] dy[t]                      (transposed low-pass, replicate pads folded into the ends)
+//   du      = dv * (1 + a * inv_b * sin(2 a u))                              (d/du [u + inv_b sin^2(a u)])
+//   dx[s]   = sum_{m,j : clamp(m+2-j) = s} 2 f[2j+1] du_even[m] + sum_{m,j : clamp(m+3-j) = s} 2 f[2j] du_odd[m]
+//   d a     = sum dv * inv_b * u * sin(2 a u),   d inv_b = sum dv * sin^2(a u)
+// One workgroup owns the dx of up to 1024 samples of one (b, c) row, recomputes u from x (+6/+6 halo) and forms the two
+// transposed filters by scatter-adding into LDS (ds_add_f32), which handles the replicate padding at the row ends with the same
+// code as the interior.  Parameter gradients: block reduction, one atomic per workgroup.  Correctness first: this kernel has not
+// been tuned (the vocoder is frozen in the reference's training_step; it matters for vocoder fine-tuning only).
+__global__ __launch_bounds__(256) void aa_snake_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            float* __restrict__ dx, const float* __restrict__ alpha,
+                                                            const float* __restrict__ beta, float* __restrict__ dalpha,
+                                                            float* __restrict__ dbeta, Taps12 tp, int logscale, int C, int T) {
+  __shared__ float xs[kSnakeTile + 12];
+  __shared__ float dys[kSnakeTile + 12];
+  __shared__ float dvs[2 * (kSnakeTile + 6)];
+  __shared__ float dxs[kSnakeTile];
+  __shared__ float red[2][4];
+  const int c = blockIdx.y, b = blockIdx.z, tid = threadIdx.x;
+  const int t0 = blockIdx.x * kSnakeTile;
+  const int len = min(kSnakeTile, T - t0);
+  const float* xr = x + ((int64_t)b * C + c) * T;
+  const float* dyr = dy + ((int64_t)b * C + c) * T;
+  float* dxr = dx + ((int64_t)b * C + c) * T;
+  float a = alpha[c], bt = beta ? beta[c] : a;
+  if (logscale) {
+    bt = beta ? expf(bt) : expf(a);
+    a = expf(a);
+  }
+  const float inv_b = 1.0f / (bt + 1e-9f);
+  for (int i = tid; i < len + 12; i += 256) {
+    const int s = t0 - 6 + i;
+    xs[i] = xr[min(max(s, 0), T - 1)];
+    dys[i] = (s >= 0 && s < T) ? dyr[s] : 0.f;
+  }
+  for (int i = tid; i < 2 * (len + 6); i += 256) dvs[i] = 0.f;
+  for (int i = tid; i < len; i += 256) dxs[i] = 0.f;
+  __syncthreads();
+  // transposed low-pass: every dy sample in reach scatters its 12 taps into the pairs this tile owns (m in [t0-3, t0+len+3))
+  for (int i = tid; i < len + 12; i += 256) {
+    const int t = t0 - 6 + i;
+    if (t < 0 || t >= T) continue;
+    const float g = dys[i];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) {
+      const int vi = min(max(2 * t + k - 5, 0), 2 * T - 1);
+      const int p = (vi >> 1) - (t0 - 3);
+      if (p >= 0 && p < len + 6) atomicAdd(&dvs[2 * p + (vi & 1)], tp.f[k] * g);
+    }
+  }
+  __syncthreads();
+  float sa = 0.f, sb = 0.f;
+  for (int p = tid; p < len + 6; p += 256) {
+    const int m = t0 - 3 + p;
+    if (m < 0 || m > T - 1) continue;
+    const float* xp = xs + (m - t0 + 6);          // xp[d] = x[clamp(m + d)] (xs holds the clamped row)
+    float ue = 0.f, uo = 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      ue = fmaf(tp.f[2 * j + 1], xp[2 - j], ue);
+      uo = fmaf(tp.f[2 * j], xp[3 - j], uo);
+    }
+    ue *= 2.f;
+    uo *= 2.f;
+    const float dve = dvs[2 * p], dvo = dvs[2 * p + 1];
+    const float s2e = sinf(2.f * a * ue), s2o = sinf(2.f * a * uo);
+    const float due = dve * fmaf(a * inv_b, s2e, 1.f), duo = dvo * fmaf(a * inv_b, s2o, 1.f);
+    if (m >= t0 && m < t0 + len) {                // parameter gradients: every pair is counted by exactly one tile
+      sa += inv_b * (dve * ue * s2e + dvo * uo * s2o);
+      sb += dve * sin_sq(a * ue) + dvo * sin_sq(a * uo);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+      const int se = min(max(m + 2 - j, 0), T - 1) - t0, so = min(max(m + 3 - j, 0), T - 1) - t0;
+      if (se >= 0 && se < len) atomicAdd(&dxs[se], 2.f * tp.f[2 * j + 1] * due);
+      if (so >= 0 && so < len) atomicAdd(&dxs[so], 2.f * tp.f[2 * j] * duo);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    sa += __shfl_xor(sa, o, 64);
+    sb += __shfl_xor(sb, o, 64);
+  }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = sa; red[1][tid >> 6] = sb; }
+  __syncthreads();
+  for (int i = tid; i < len; i += 256) dxr[t0 + i] = dxs[i];
+  if (tid == 0) {
+    const float ga = red[0][0] + red[0][1] + red[0][2] + red[0][3];        // d loss / d a'      (a' = effective alpha)
+    const float gib = red[1][0] + red[1][1] + red[1][2] + red[1][3];       // d loss / d inv_b
+    const float gb = -inv_b * inv_b * gib;                                 // d loss / d b'      (inv_b = 1 / (b' + 1e-9))
+    if (beta) {
+      atomicAdd(&dalpha[c], logscale ? ga * a : ga);
+      atomicAdd(&dbeta[c], logscale ? gb * bt : gb);
+    } else {
+      atomicAdd(&dalpha[c], logscale ? (ga + gb) * a : ga + gb);           // Snake: b' = a'
+    }
+  }
+}
+
+int launch_aa_snake_bwd(const float* x, const float* dy, float* dx, const float* alpha, const float* beta, float* dalpha, float* dbeta,
+                        const float* taps_host, int logscale, int B, int C, int64_t T, hipStream_t s) {
+  DMEL_CHECK_ARG(x && dy && dx && alpha && dalpha && taps_host, "aa_snake_backward: NULL argument");
+  DMEL_CHECK_ARG((beta != nullptr) == (dbeta != nullptr), "aa_snake_backward: dbeta must be given exactly when beta is");
+  DMEL_CHECK_ARG(B > 0 && C > 0 && T > 0 && B <= 65535 && C <= 65535 && T < ((int64_t)1 << 29), "aa_snake_backward: bad shape");
+  Taps12 tp;
+  for (int i = 0; i < 12; ++i) tp.f[i] = taps_host[i];
+  DMEL_HIP(hipMemsetAsync(dalpha, 0, (size_t)C * sizeof(float), s));
+  if (dbeta) DMEL_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s));
+  dim3 grid((unsigned)((T + kSnakeTile - 1) / kSnakeTile), (unsigned)C, (unsigned)B);
+  {
+    ProfScope ps("aa_snake_bwd", s, 0.0, 12.0 * (double)B * C * (double)T);
+    hipLaunchKernelGGL(aa_snake_bwd_kernel, grid, dim3(256), 0, s, x, dy, dx, alpha, beta, dalpha, dbeta, tp, logscale, C, (int)T);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
 int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host, int logscale,
                     int B, int C, int64_t T, hipStream_t s) {
   DMEL_CHECK_ARG(x && y && alpha && taps_host, "aa_snake: NULL argument");
@@ -137,6 +256,12 @@ int launch_aa_snake(const float* x, float* y, const float* alpha, const float* b
 }
 
 }  // namespace dmel
+
+extern "C" int dmel_aa_snake_backward_f32(const float* x, const float* dy, float* dx, const float* alpha, const float* beta,
+                                          float* dalpha, float* dbeta, const float* filter12_host, int logscale, int B, int C, int64_t T,
+                                          void* stream) {
+  return dmel::launch_aa_snake_bwd(x, dy, dx, alpha, beta, dalpha, dbeta, filter12_host, logscale, B, C, T, (hipStream_t)stream);
+}
 
 extern "C" int dmel_aa_snake_f32(const float* x, float* y, const float* alpha, const float* beta, const float* filter12_host,
                                  int logscale, int B, int C, int64_t T, void* stream) {

@@ -85,6 +85,13 @@ int dmel_stft_logmel_f32(const dmel_stft_plan* plan, const float* audio, int64_t
  * ---------------------------------------------------------------------------------------------- */
 int dmel_aa_snake_f32(const float* x, float* y, const float* alpha, const float* beta, const float* filter12_host,
                       int logscale, int B, int C, int64_t T, void* stream);
+/* Backward of dmel_aa_snake_f32 (the reference's fused kernel has none: alias_free_activation/cuda/activation1d.py:29-32;
+ * SURVEY.md section 8(f) rank 1, C-ABI row `aa_snake(+_bwd)`): dx (B, C, T), dalpha (C), dbeta (C; NULL exactly when beta is NULL,
+ * i.e. Snake, whose single parameter then receives both contributions).  Gradients are with respect to the STORED parameters
+ * (the log-scale ones when logscale != 0).  dalpha / dbeta are overwritten.  Summation order is not fixed (atomics). */
+int dmel_aa_snake_backward_f32(const float* x, const float* dy, float* dx, const float* alpha, const float* beta /*nullable*/,
+                               float* dalpha, float* dbeta /*nullable*/, const float* filter12_host, int logscale, int B, int C,
+                               int64_t T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Module handles.  Weights are handed over as HOST fp32 arrays under the reference's state-dict key names
