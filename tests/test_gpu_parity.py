@@ -799,3 +799,25 @@ def test_activation1d_backward_matches_autograd(dev, B, Cc, T, kind):
     # beta / dbeta must be given together
     assert L.dmel_aa_snake_backward_f32(xd.data_ptr(), dyd.data_ptr(), dx.data_ptr(), ad.data_ptr(), None, da.data_ptr(),
                                         da.data_ptr(), taps.data_ptr(), int(logscale), B, Cc, T, _lib.stream_ptr()) < 0
+
+
+def test_activation1d_module_is_differentiable(dev):
+    from dmel_codec_amd.models.modules.bigvgan.alias_free_activation.act import Activation1d
+    from dmel_codec_amd.models.modules.bigvgan import activations
+    torch.manual_seed(3)
+    m = Activation1d(activation=activations.SnakeBeta(6, alpha_logscale=True)).to(dev)
+    with torch.no_grad():
+        m.act.alpha.normal_(0, 0.3)
+        m.act.beta.normal_(0, 0.3)
+    x = torch.randn(2, 6, 300, device=dev, requires_grad=True)
+    g = torch.randn(2, 6, 300, device=dev)
+    y = m(x)
+    (y * g).sum().backward()
+    x64 = x.detach().cpu().double().requires_grad_()
+    a64, b64 = m.act.alpha.detach().cpu().double().requires_grad_(), m.act.beta.detach().cpu().double().requires_grad_()
+    y64 = ref_cpu.activation1d(x64, a64, b64, ref_cpu.aa_filter12().double(), None, logscale=True)
+    (y64 * g.cpu().double()).sum().backward()
+    assert rel_err(y, y64) < 1e-5 and rel_err(x.grad, x64.grad) < 2e-5
+    assert rel_err(m.act.alpha.grad, a64.grad) < 1e-4 and rel_err(m.act.beta.grad, b64.grad) < 1e-4
+    with torch.no_grad():
+        assert torch.equal(m(x.detach()), y.detach())
