@@ -50,6 +50,18 @@ PROTOTYPES = {
     "dmel_stft_logmel_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_aa_snake_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_aa_snake_backward_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    "dmel_convnext_create": (C.c_int, [C.POINTER(vp), C.c_int]),
+    "dmel_convnext_destroy": (None, [vp]),
+    "dmel_convnext_set_tensor": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]),
+    "dmel_convnext_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_convnext_finalize": (C.c_int, [vp]),
+    "dmel_convnext_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
+    "dmel_convnext_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
+    "dmel_convnext_train_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
+    "dmel_convnext_grad_floats": (C.c_int64, [vp]),
+    "dmel_convnext_grad_slot": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "dmel_convnext_forward_train": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
+    "dmel_convnext_backward": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_wavenet_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmel_wavenet_destroy": (None, [vp]),
     "dmel_wavenet_set_precision": (C.c_int, [vp, C.c_int]),

@@ -639,6 +639,161 @@ int run_convnext(const ConvNeXt& cx, const float* x, float* y, float* h1, float*
 }
 }  // namespace
 
+// ---- standalone ConvNeXtBlock handle (firefly.py:337-402), inference and training -----------------------------------
+struct dmel_convnext {
+  int C = 0;
+  TensorStore ts;
+  bool ready = false, train = false, train_ready = false;
+  ConvNeXt cx;
+  PackedConv pw1T, pw2T;          // transposed images: backward-data of the two Linear layers
+  struct GradSlot { std::string key; int64_t offset, numel; };
+  std::vector<GradSlot> slots;
+  int64_t grad_floats = 0;
+};
+
+extern "C" int dmel_convnext_create(dmel_convnext** out, int dim) {
+  DMEL_CHECK_ARG(out && dim > 0, "convnext_create: bad argument");
+  auto* m = new dmel_convnext();
+  m->C = dim;
+  *out = m;
+  return DMEL_OK;
+}
+extern "C" void dmel_convnext_destroy(dmel_convnext* m) { delete m; }
+extern "C" int dmel_convnext_set_tensor(dmel_convnext* m, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  m->ready = false;
+  return m->ts.set(key, data, shape, ndim);
+}
+extern "C" int dmel_convnext_enable_training(dmel_convnext* m, int on) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  m->train = on != 0;
+  m->ready = false;
+  m->train_ready = false;
+  return DMEL_OK;
+}
+extern "C" int dmel_convnext_finalize(dmel_convnext* m) {
+  DMEL_CHECK_ARG(m, "NULL handle");
+  const int C = m->C;
+  DMEL_TRY(build_convnext(m->cx, m->ts, "", C));
+  if (m->train) {
+    const HostTensor* w1 = m->ts.need("pwconv1.weight", {4 * C, C});
+    const HostTensor* w2 = m->ts.need("pwconv2.weight", {C, 4 * C});
+    if (!w1 || !w2) return DMEL_EMISSING;
+    PackDesc d;
+    d.mode = EPI_LINEAR; d.nseg = 1; d.C = C; d.seg[0].Cin = 4 * C;          // d u (4C) -> d h1 (C): W1^T
+    DMEL_TRY(pack_conv(m->pw1T, d, [&](int, int row, int cc, int) { return w1->v[(size_t)cc * C + row]; }, [&](int) { return 0.f; }));
+    d.C = 4 * C; d.seg[0].Cin = C;                                           // d v (C) -> d g (4C): W2^T
+    DMEL_TRY(pack_conv(m->pw2T, d, [&](int, int row, int cc, int) { return w2->v[(size_t)cc * 4 * C + row]; }, [&](int) { return 0.f; }));
+    m->slots.clear();
+    int64_t off = 0;
+    auto slot = [&](const char* key, int64_t numel) { m->slots.push_back({key, off, numel}); off += numel; };
+    slot("dwconv.weight", (int64_t)C * 7); slot("dwconv.bias", C); slot("norm.weight", C); slot("norm.bias", C);
+    slot("pwconv1.weight", (int64_t)4 * C * C); slot("pwconv1.bias", 4 * C); slot("pwconv2.weight", (int64_t)4 * C * C);
+    slot("pwconv2.bias", C); slot("gamma", C);
+    m->grad_floats = off;
+    m->train_ready = true;
+  }
+  m->ts.t.clear();
+  m->ready = true;
+  return DMEL_OK;
+}
+extern "C" size_t dmel_convnext_workspace_bytes(const dmel_convnext* m, int N, int64_t T) {
+  if (!m || N <= 0 || T <= 0) return 0;
+  return align_up((size_t)5 * N * m->C * T * sizeof(float), 256);
+}
+extern "C" int dmel_convnext_forward(const dmel_convnext* m, const float* x, float* y, int N, int64_t T, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(m && x && y && workspace, "convnext_forward: NULL argument");
+  if (!m->ready) { set_error("convnext_forward: handle not finalized"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(N > 0 && T > 0 && workspace_bytes >= dmel_convnext_workspace_bytes(m, N, T), "convnext_forward: bad shape or workspace");
+  float* h1 = reinterpret_cast<float*>(workspace);
+  return run_convnext(m->cx, x, y, h1, h1 + (size_t)N * m->C * T, N, m->C, T, (hipStream_t)stream);
+}
+
+namespace {
+struct CxPlan { float *H0, *H1, *U, *G, *V, *DV, *DG, *DH1, *DH0; size_t n, bytes; };
+CxPlan cx_plan(const dmel_convnext* m, int N, int64_t T, void* ws) {
+  CxPlan p{};
+  Arena a(ws, (size_t)-1);
+  const size_t n = (size_t)N * m->C * T;
+  p.n = n;
+  p.H0 = a.take<float>(n); p.H1 = a.take<float>(n); p.U = a.take<float>(4 * n); p.G = a.take<float>(4 * n); p.V = a.take<float>(n);
+  p.DV = a.take<float>(n); p.DG = a.take<float>(4 * n); p.DH1 = a.take<float>(n); p.DH0 = a.take<float>(n);
+  p.bytes = align_up(a.off, 256);
+  return p;
+}
+}  // namespace
+
+extern "C" size_t dmel_convnext_train_workspace_bytes(const dmel_convnext* m, int N, int64_t T) {
+  if (!m || N <= 0 || T <= 0) return 0;
+  return cx_plan(m, N, T, nullptr).bytes;
+}
+extern "C" int64_t dmel_convnext_grad_floats(const dmel_convnext* m) { return m && m->train_ready ? m->grad_floats : 0; }
+extern "C" int dmel_convnext_grad_slot(const dmel_convnext* m, const char* key, int64_t* offset, int64_t* numel) {
+  DMEL_CHECK_ARG(m && key && offset && numel, "convnext_grad_slot: NULL argument");
+  if (!m->train_ready) { set_error("convnext_grad_slot: training was not enabled before finalize"); return DMEL_EMISSING; }
+  for (const auto& s : m->slots)
+    if (s.key == key) { *offset = s.offset; *numel = s.numel; return DMEL_OK; }
+  set_error("convnext_grad_slot: '%s' is not a parameter of ConvNeXtBlock", key);
+  return DMEL_EINVAL;
+}
+
+// firefly.py:383-402 unfused, keeping the pre-norm, normed, pre-GELU, post-GELU and pre-scale tensors for backward
+extern "C" int dmel_convnext_forward_train(const dmel_convnext* m, const float* x, float* y, int N, int64_t T, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(m && x && y && workspace, "convnext_forward_train: NULL argument");
+  if (!m->ready || !m->train_ready) { set_error("convnext_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(N > 0 && T > 0, "convnext_forward_train: bad shape");
+  const CxPlan p = cx_plan(m, N, T, workspace);
+  DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "convnext_forward_train: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = m->C;
+  const ConvNeXt& cx = m->cx;
+  DMEL_TRY(launch_dwconv_ln(x, p.H1, cx.dw_w.as<float>(), cx.dw_b.as<float>(), cx.ln_w.as<float>(), cx.ln_b.as<float>(), N, C, T, st, p.H0));
+  ConvRun a = run_1seg(p.H1, C, T, p.U, 4 * C, T, N);
+  DMEL_TRY(launch_conv(cx.pw1, a, st));
+  DMEL_TRY(launch_gelu_fwd(p.U, p.G, (int64_t)(4 * p.n), st));
+  ConvRun b = run_1seg(p.G, 4 * C, T, p.V, C, T, N);
+  DMEL_TRY(launch_conv(cx.pw2, b, st));
+  return launch_layerscale_res_fwd(x, p.V, cx.gamma.as<float>(), y, N, C, T, st);
+}
+
+extern "C" int dmel_convnext_backward(const dmel_convnext* m, const float* x, const float* dy, float* dx, float* grads, int N, int64_t T,
+                                      void* workspace, size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(m && x && dy && dx && grads && workspace, "convnext_backward: NULL argument");
+  if (!m->ready || !m->train_ready) { set_error("convnext_backward: enable_training + finalize first"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(N > 0 && T > 0, "convnext_backward: bad shape");
+  const CxPlan p = cx_plan(m, N, T, workspace);
+  DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "convnext_backward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = m->C;
+  const ConvNeXt& cx = m->cx;
+  auto G = [&](const char* key) -> float* {
+    for (const auto& s : m->slots)
+      if (s.key == key) return grads + s.offset;
+    return nullptr;
+  };
+  // y = x + gamma * V
+  DMEL_TRY(launch_layerscale_bwd(dy, p.V, cx.gamma.as<float>(), p.DV, G("gamma"), N, C, T, st));
+  // V = pwconv2(G)
+  DMEL_TRY(launch_conv_wgrad(p.G, p.DV, G("pwconv2.weight"), G("pwconv2.bias"), C, 4 * C, 1, 1, N, T, st));
+  {
+    ConvRun r = run_1seg(p.DV, C, T, p.DG, 4 * C, T, N);
+    DMEL_TRY(launch_conv(m->pw2T, r, st));
+  }
+  // G = gelu(U)   (d U overwrites d G)
+  DMEL_TRY(launch_gelu_bwd(p.DG, p.U, p.DG, (int64_t)(4 * p.n), st));
+  // U = pwconv1(H1)
+  DMEL_TRY(launch_conv_wgrad(p.H1, p.DG, G("pwconv1.weight"), G("pwconv1.bias"), 4 * C, C, 1, 1, N, T, st));
+  {
+    ConvRun r = run_1seg(p.DG, 4 * C, T, p.DH1, C, T, N);
+    DMEL_TRY(launch_conv(m->pw1T, r, st));
+  }
+  // H1 = LayerNorm(H0), H0 = dwconv(x); dx = dy (identity path) + dwconv^T(d H0)
+  DMEL_TRY(launch_ln_bwd(p.DH1, p.H0, cx.ln_w.as<float>(), p.DH0, G("norm.weight"), G("norm.bias"), N, C, T, st));
+  return launch_dwconv_bwd(p.DH0, x, cx.dw_w.as<float>(), dy, dx, G("dwconv.weight"), G("dwconv.bias"), N, C, T, st);
+}
+
 struct dmel_quantizer {
   int dim, G, Cg, D, nf;
   int factors[4];

@@ -16,8 +16,9 @@ int launch_fsq_encode(const float* z, const float* w_in, const float* b_in, int3
                       const FsqConst& k, int B, int G, int C, int64_t T4, hipStream_t s);
 int launch_fsq_decode(const int32_t* ids, const float* w_out, const float* b_out, float* z, const FsqConst& k, int B,
                       int G, int C, int64_t T4, hipStream_t s);
+// h0 (nullable): also store the pre-norm depthwise-conv output (N, C, T) -- the training path keeps it for the LayerNorm backward
 int launch_dwconv_ln(const float* x, float* y, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
-                     int N, int C, int64_t T, hipStream_t s);
+                     int N, int C, int64_t T, hipStream_t s, float* h0 = nullptr);
 // act: 2 = tanh, 3 = clamp(-1, 1), else none (values of enum Act)
 int launch_conv_post(const float* x, float* y, const float* w_dev, float bias, int act, int B, int C, int K, int64_t T,
                      hipStream_t s);
@@ -34,6 +35,20 @@ int launch_resskip_bwd(const float* gx, const float* gs, float* go, float* gxs, 
 int launch_silu_fwd(const float* u, float* y, int64_t total, hipStream_t s);
 int launch_silu_bwd(const float* g, const float* u, float* du, int64_t total, hipStream_t s);
 int launch_scale(const float* x, float* y, float k, int64_t total, hipStream_t s);
+// ConvNeXt block pieces (firefly.py:383-402): exact-erf GELU, layer scale + residual, and the backward of the front half
+int launch_gelu_fwd(const float* u, float* g, int64_t total, hipStream_t s);
+int launch_gelu_bwd(const float* dg, const float* u, float* du, int64_t total, hipStream_t s);
+int launch_layerscale_res_fwd(const float* x, const float* v, const float* gamma, float* y, int N, int C, int64_t T, hipStream_t s);
+// dv = dy * gamma[c]; dgamma[c] = sum_{n,t} dy * v   (dgamma overwritten)
+int launch_layerscale_bwd(const float* dy, const float* v, const float* gamma, float* dv, float* dgamma, int N, int C, int64_t T,
+                          hipStream_t s);
+// LayerNorm over channels (eps 1e-6, biased variance) backward: dh0 from dh1 and the saved pre-norm h0; dln_w / dln_b accumulated
+// with atomics into zero-initialised buffers
+int launch_ln_bwd(const float* dh1, const float* h0, const float* ln_w, float* dh0, float* dln_w, float* dln_b, int N, int C, int64_t T,
+                  hipStream_t s);
+// depthwise k=7 conv backward: dx = dres + conv_transpose(dh0) (dres nullable), ddw (C, 7), ddb (C) overwritten
+int launch_dwconv_bwd(const float* dh0, const float* x, const float* dw_w, const float* dres, float* dx, float* ddw, float* ddb, int N, int C,
+                      int64_t T, hipStream_t s);
 // dw (Cout, Cin, taps) = sum_{b,t} dy[b,co,t] * x[b,ci,t + k*dil - pad], pad = dil*(taps-1)/2; db (Cout) nullable.  Overwrites.
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int Cout, int Cin, int taps, int dil, int B, int64_t T,
                       hipStream_t s);

@@ -11,6 +11,7 @@ constexpr int kDwTile = 32;
 __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         const float* __restrict__ dw_w, const float* __restrict__ dw_b,
                                                         const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+                                                        float* __restrict__ h0 /*nullable: pre-norm output, kept for training*/,
                                                         int C, int64_t T, float eps) {
   extern __shared__ float sm[];
   float* hbuf = sm;                         // [C][kDwTile+1]
@@ -52,19 +53,22 @@ __global__ __launch_bounds__(256) void dwconv_ln_kernel(const float* __restrict_
   for (int idx = tid; idx < C * kDwTile; idx += 256) {
     const int c = idx / kDwTile, j = idx % kDwTile;
     const int64_t t = t0 + j;
-    if (t < T) yn[(int64_t)c * T + t] = (hbuf[c * (kDwTile + 1) + j] - stat[j]) * stat[kDwTile + j] * ln_w[c] + ln_b[c];
+    if (t < T) {
+      yn[(int64_t)c * T + t] = (hbuf[c * (kDwTile + 1) + j] - stat[j]) * stat[kDwTile + j] * ln_w[c] + ln_b[c];
+      if (h0) h0[((int64_t)n * C + c) * T + t] = hbuf[c * (kDwTile + 1) + j];
+    }
   }
 }
 
 int launch_dwconv_ln(const float* x, float* y, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
-                     int N, int C, int64_t T, hipStream_t s) {
+                     int N, int C, int64_t T, hipStream_t s, float* h0) {
   DMEL_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0, "dwconv_ln: bad shape");
   const size_t lds = ((size_t)C * (kDwTile + 1) + 2 * kDwTile) * sizeof(float);
   DMEL_CHECK_ARG(lds <= 64 * 1024, "dwconv_ln: %d channels exceed the LDS tile", C);
   dim3 grid((unsigned)((T + kDwTile - 1) / kDwTile), (unsigned)N);
   {
     ProfScope ps("small", s, 0.0, 8.0 * N * C * (double)T);
-    hipLaunchKernelGGL(dwconv_ln_kernel, grid, dim3(256), lds, s, x, y, dw_w, dw_b, ln_w, ln_b, C, T, 1e-6f);
+    hipLaunchKernelGGL(dwconv_ln_kernel, grid, dim3(256), lds, s, x, y, dw_w, dw_b, ln_w, ln_b, h0, C, T, 1e-6f);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;

@@ -72,6 +72,158 @@ __global__ void scale_kernel(const float* __restrict__ x, float* __restrict__ y,
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) y[i] = x[i] * k;
 }
 
+// ---- ConvNeXt block pieces ------------------------------------------------------------------------------------------
+__global__ void gelu_fwd_kernel(const float* __restrict__ u, float* __restrict__ g, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = u[i];
+    g[i] = 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+  }
+}
+// d gelu(u) / du = Phi(u) + u * phi(u)
+__global__ void gelu_bwd_kernel(const float* dg, const float* __restrict__ u, float* du, int64_t total) {   // du may alias dg
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = u[i];
+    const float cdf = 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * expf(-0.5f * v * v);
+    du[i] = dg[i] * (cdf + v * pdf);
+  }
+}
+__global__ void layerscale_res_fwd_kernel(const float* __restrict__ x, const float* __restrict__ v, const float* __restrict__ gamma,
+                                          float* __restrict__ y, int C, int64_t T, int64_t total) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / T) % C);
+    y[i] = x[i] + gamma[c] * v[i];
+  }
+}
+// one workgroup per channel: dv = dy * gamma[c]; dgamma[c] = sum dy * v
+__global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ v,
+                                                             const float* __restrict__ gamma, float* __restrict__ dv,
+                                                             float* __restrict__ dgamma, int N, int C, int T) {
+  __shared__ float part[4];
+  const int c = blockIdx.x;
+  const float g = gamma[c];
+  float s = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int64_t base = ((int64_t)n * C + c) * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float d = dy[base + t];
+      s = fmaf(d, v[base + t], s);
+      dv[base + t] = d * g;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dgamma[c] = part[0] + part[1] + part[2] + part[3];
+}
+
+constexpr int kLnTile = 32;
+// grid (ceil(T/32), N): a [C][32] tile of h0 and dh1 in LDS; statistics per column by one lane, then the per-element update;
+// per-channel parameter sums over the tile's columns go out as one atomic per channel and workgroup.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dh1, const float* __restrict__ h0,
+                                                     const float* __restrict__ ln_w, float* __restrict__ dh0, float* __restrict__ dln_w,
+                                                     float* __restrict__ dln_b, int C, int64_t T, float eps) {
+  extern __shared__ float lsm[];
+  float* hb = lsm;                                  // [C][33]  h0, then xhat
+  float* gb = lsm + (size_t)C * (kLnTile + 1);      // [C][33]  dh1
+  float* st = gb + (size_t)C * (kLnTile + 1);       // [4][32]  mean, rstd, s1, s2
+  const int tid = threadIdx.x, n = blockIdx.y;
+  const int64_t t0 = (int64_t)blockIdx.x * kLnTile;
+  const int64_t base = (int64_t)n * C * T;
+  for (int idx = tid; idx < C * kLnTile; idx += 256) {
+    const int c = idx / kLnTile, j = idx % kLnTile;
+    const int64_t t = t0 + j;
+    const bool ok = t < T;
+    hb[c * (kLnTile + 1) + j] = ok ? h0[base + (int64_t)c * T + t] : 0.f;
+    gb[c * (kLnTile + 1) + j] = ok ? dh1[base + (int64_t)c * T + t] : 0.f;
+  }
+  __syncthreads();
+  if (tid < kLnTile) {
+    float mean = 0.f;
+    for (int c = 0; c < C; ++c) mean += hb[c * (kLnTile + 1) + tid];
+    mean /= (float)C;
+    float var = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float d = hb[c * (kLnTile + 1) + tid] - mean;
+      var = fmaf(d, d, var);
+    }
+    var /= (float)C;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = 0; c < C; ++c) {
+      const float xh = (hb[c * (kLnTile + 1) + tid] - mean) * rstd;
+      const float dxh = gb[c * (kLnTile + 1) + tid] * ln_w[c];
+      s1 += dxh;
+      s2 = fmaf(dxh, xh, s2);
+    }
+    st[tid] = mean; st[kLnTile + tid] = rstd; st[2 * kLnTile + tid] = s1 / (float)C; st[3 * kLnTile + tid] = s2 / (float)C;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < C * kLnTile; idx += 256) {
+    const int c = idx / kLnTile, j = idx % kLnTile;
+    const int64_t t = t0 + j;
+    const float xh = (hb[c * (kLnTile + 1) + j] - st[j]) * st[kLnTile + j];
+    hb[c * (kLnTile + 1) + j] = xh;                  // keep xhat for the parameter sums
+    if (t < T) dh0[base + (int64_t)c * T + t] = st[kLnTile + j] * (gb[c * (kLnTile + 1) + j] * ln_w[c] - st[2 * kLnTile + j] - xh * st[3 * kLnTile + j]);
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    float sw = 0.f, sb = 0.f;
+    for (int j = 0; j < kLnTile; ++j) {              // out-of-range columns hold dh1 = 0
+      const float g = gb[c * (kLnTile + 1) + j];
+      sw = fmaf(g, hb[c * (kLnTile + 1) + j], sw);
+      sb += g;
+    }
+    atomicAdd(&dln_w[c], sw);
+    atomicAdd(&dln_b[c], sb);
+  }
+}
+
+// one workgroup per channel: dx[c, t] = dres + sum_k w[c, k] dh0[c, t - k + 3];  ddw[c, k] = sum dh0[c, t] x[c, t + k - 3];  ddb = sum dh0
+__global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict__ dh0, const float* __restrict__ x,
+                                                         const float* __restrict__ dw_w, const float* __restrict__ dres,
+                                                         float* __restrict__ dx, float* __restrict__ ddw, float* __restrict__ ddb, int N,
+                                                         int C, int T) {
+  __shared__ float part[8][4];
+  const int c = blockIdx.x;
+  float w[7];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) w[k] = dw_w[c * 7 + k];
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const int64_t base = ((int64_t)n * C + c) * T;
+    for (int t = threadIdx.x; t < T; t += 256) {
+      const float g = dh0[base + t];
+      float d = dres ? dres[base + t] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int td = t - k + 3;                       // y[td] used x[td + k - 3] = x[t]
+        if (td >= 0 && td < T) d = fmaf(w[k], dh0[base + td], d);
+        const int tx = t + k - 3;
+        if (tx >= 0 && tx < T) acc[k] = fmaf(g, x[base + tx], acc[k]);
+      }
+      acc[7] += g;
+      dx[base + t] = d;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    float s = acc[k];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) part[k][threadIdx.x >> 6] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    const float s = part[threadIdx.x][0] + part[threadIdx.x][1] + part[threadIdx.x][2] + part[threadIdx.x][3];
+    if (threadIdx.x < 7) ddw[c * 7 + threadIdx.x] = s;
+    else ddb[c] = s;
+  }
+}
+
 unsigned blocks_for(int64_t total) { return (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 32); }
 
 }  // namespace
@@ -193,6 +345,40 @@ int launch_resskip_bwd(const float* gx, const float* gs, float* go, float* gxs, 
 int launch_silu_fwd(const float* u, float* y, int64_t total, hipStream_t s) { DMEL_EW_LAUNCH(silu_fwd_kernel, total, 8, u, y, total); }
 int launch_silu_bwd(const float* g, const float* u, float* du, int64_t total, hipStream_t s) {
   DMEL_EW_LAUNCH(silu_bwd_kernel, total, 12, g, u, du, total);
+}
+int launch_gelu_fwd(const float* u, float* g, int64_t total, hipStream_t s) { DMEL_EW_LAUNCH(gelu_fwd_kernel, total, 8, u, g, total); }
+int launch_gelu_bwd(const float* dg, const float* u, float* du, int64_t total, hipStream_t s) {
+  DMEL_EW_LAUNCH(gelu_bwd_kernel, total, 12, dg, u, du, total);
+}
+int launch_layerscale_res_fwd(const float* x, const float* v, const float* gamma, float* y, int N, int C, int64_t T, hipStream_t s) {
+  const int64_t total = (int64_t)N * C * T;
+  DMEL_EW_LAUNCH(layerscale_res_fwd_kernel, total, 12, x, v, gamma, y, C, T, total);
+}
+int launch_layerscale_bwd(const float* dy, const float* v, const float* gamma, float* dv, float* dgamma, int N, int C, int64_t T,
+                          hipStream_t s) {
+  DMEL_CHECK_ARG(T < ((int64_t)1 << 31), "layerscale_bwd: T too large");
+  hipLaunchKernelGGL(layerscale_bwd_kernel, dim3((unsigned)C), dim3(256), 0, s, dy, v, gamma, dv, dgamma, N, C, (int)T);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+int launch_ln_bwd(const float* dh1, const float* h0, const float* ln_w, float* dh0, float* dln_w, float* dln_b, int N, int C, int64_t T,
+                  hipStream_t s) {
+  DMEL_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0, "ln_bwd: bad shape");
+  const size_t lds = ((size_t)2 * C * (kLnTile + 1) + 4 * kLnTile) * sizeof(float);
+  DMEL_CHECK_ARG(lds <= 64 * 1024, "ln_bwd: %d channels exceed the LDS tile", C);
+  DMEL_HIP(hipMemsetAsync(dln_w, 0, (size_t)C * sizeof(float), s));
+  DMEL_HIP(hipMemsetAsync(dln_b, 0, (size_t)C * sizeof(float), s));
+  dim3 grid((unsigned)((T + kLnTile - 1) / kLnTile), (unsigned)N);
+  hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), lds, s, dh1, h0, ln_w, dh0, dln_w, dln_b, C, T, 1e-6f);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+int launch_dwconv_bwd(const float* dh0, const float* x, const float* dw_w, const float* dres, float* dx, float* ddw, float* ddb, int N, int C,
+                      int64_t T, hipStream_t s) {
+  DMEL_CHECK_ARG(T < ((int64_t)1 << 31), "dwconv_bwd: T too large");
+  hipLaunchKernelGGL(dwconv_bwd_kernel, dim3((unsigned)C), dim3(256), 0, s, dh0, x, dw_w, dres, dx, ddw, ddb, N, C, (int)T);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
 }
 int launch_scale(const float* x, float* y, float k, int64_t total, hipStream_t s) { DMEL_EW_LAUNCH(scale_kernel, total, 8, x, y, k, total); }
 

@@ -139,6 +139,28 @@ int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, const float* co
                           float* dcondition /*nullable*/, float* grads, int N, int64_t T, void* workspace, size_t workspace_bytes,
                           void* stream);
 
+/* ConvNeXtBlock (models/modules/firefly.py:337-402; C-ABI row `convnext_block`), standalone: y = x + gamma * pwconv2(gelu(pwconv1(
+ * LayerNorm_C(dwconv7(x))))), x / y (N, dim, T).  set_tensor keys: dwconv.weight (dim,1,7), dwconv.bias, norm.weight, norm.bias,
+ * pwconv1.weight (4 dim, dim), pwconv1.bias, pwconv2.weight (dim, 4 dim), pwconv2.bias, gamma.  The training entry points follow the
+ * WaveNet ones (enable_training before finalize; forward_train keeps its intermediates in the workspace that backward is given again;
+ * parameter gradients in one flat buffer addressed through grad_slot; dx is always produced). */
+typedef struct dmel_convnext dmel_convnext;
+int dmel_convnext_create(dmel_convnext** m, int dim);
+void dmel_convnext_destroy(dmel_convnext* m);
+int dmel_convnext_set_tensor(dmel_convnext* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int dmel_convnext_enable_training(dmel_convnext* m, int on);
+int dmel_convnext_finalize(dmel_convnext* m);
+size_t dmel_convnext_workspace_bytes(const dmel_convnext* m, int N, int64_t T);
+int dmel_convnext_forward(const dmel_convnext* m, const float* x, float* y, int N, int64_t T, void* workspace, size_t workspace_bytes,
+                          void* stream);
+size_t dmel_convnext_train_workspace_bytes(const dmel_convnext* m, int N, int64_t T);
+int64_t dmel_convnext_grad_floats(const dmel_convnext* m);
+int dmel_convnext_grad_slot(const dmel_convnext* m, const char* key, int64_t* offset, int64_t* numel);
+int dmel_convnext_forward_train(const dmel_convnext* m, const float* x, float* y, int N, int64_t T, void* workspace,
+                                size_t workspace_bytes, void* stream);
+int dmel_convnext_backward(const dmel_convnext* m, const float* x, const float* dy, float* dx, float* grads, int N, int64_t T,
+                           void* workspace, size_t workspace_bytes, void* stream);
+
 /* DownsampleFiniteScalarQuantize (is_dmel=True, n_codebooks=1)   replaces models/modules/dowmsample_fsq.py:124-147
  * and vector_quantize_pytorch GroupedResidualFSQ.forward / get_output_from_indices. */
 typedef struct dmel_quantizer dmel_quantizer;

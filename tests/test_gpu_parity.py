@@ -821,3 +821,34 @@ def test_activation1d_module_is_differentiable(dev):
     assert rel_err(m.act.alpha.grad, a64.grad) < 1e-4 and rel_err(m.act.beta.grad, b64.grad) < 1e-4
     with torch.no_grad():
         assert torch.equal(m(x.detach()), y.detach())
+
+
+@pytest.mark.parametrize("dim,N,T", [(70, 6, 46), (70, 3, 23), (16, 2, 100), (48, 4, 33)])
+def test_convnext_block_forward_backward(dev, dim, N, T):
+    """Standalone ConvNeXtBlock: inference forward, forward_train and the hand-written backward (LayerNorm-over-channels, depthwise
+    conv, exact-erf GELU, layer scale) against autograd through the oracle in float64 -- input gradient and all nine parameters."""
+    from dmel_codec_amd.models.modules.firefly import ConvNeXtBlock
+    torch.manual_seed(dim + T)
+    m = ConvNeXtBlock(dim)
+    randomise(m, 11 + dim)
+    with torch.no_grad():
+        m.gamma.normal_(0, 0.5)          # the reference initialises gamma to 1e-6, which would hide every inner gradient
+        m.norm.weight.normal_(1, 0.3)
+        m.norm.bias.normal_(0, 0.3)
+    sd64 = {k: v.double().requires_grad_() for k, v in cpu_sd(m).items()}
+    x = torch.randn(N, dim, T)
+    gy = torch.randn(N, dim, T)
+    x64 = x.double().requires_grad_()
+    y64 = ref_cpu.convnext_block(sd64, "", x64)
+    (y64 * gy.double()).sum().backward()
+    m = m.to(dev)
+    xd = x.to(dev).requires_grad_()
+    with torch.no_grad():
+        y_inf = m(xd.detach())
+    y = m(xd)
+    assert rel_err(y_inf, y64) < 2e-5 and rel_err(y, y64) < 2e-5
+    (y * gy.to(dev)).sum().backward()
+    assert rel_err(xd.grad, x64.grad) < 2e-5
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad, sd64[k].grad) < 5e-5, (k, rel_err(p.grad, sd64[k].grad))
