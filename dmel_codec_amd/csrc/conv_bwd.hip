@@ -26,6 +26,9 @@ struct WgArgs {
   float* dw;
   int Cout, Cin, taps, dil, pad, B, T;
   int chunks_per_item, slices, chunks_per_slice;
+  // strided form (k2s2 conv / transposed conv): x[b, ci, t * xstride + xoff] of rows of length Tx; the result of the single
+  // launch tap goes to dw[(co * Cin + ci) * taps_out + tap_out]
+  int xstride, xoff, Tx, taps_out, tap_out;
 };
 
 // grid (ceil(Cin/64), ceil(Cout/64), taps * slices); 256 threads = 2 x 2 waves of 32 x 32
@@ -47,17 +50,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   for (int c = c_begin; c < c_end; ++c) {
     const int b = c / a.chunks_per_item, t0 = (c - b * a.chunks_per_item) * kWgK;
     const float* dyb = a.dy + (int64_t)b * a.Cout * a.T;
-    const float* xb = a.x + (int64_t)b * a.Cin * a.T;
+    const float* xb = a.x + (int64_t)b * a.Cin * a.Tx;
     // stage dy[co0 .. co0+63][t0 .. t0+63] and x[ci0 .. ci0+63][t0+shift ..]: one 256-byte row segment per wave and pass
     float vd[16], vx[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = wave + 4 * i;
-      const int t = t0 + lane, tx = t + shift;
+      const int t = t0 + lane, tx = t * a.xstride + a.xoff + shift;
       const int co = co0 + row, ci = ci0 + row;
-      const bool okd = co < a.Cout && t < a.T, okx = ci < a.Cin && t < a.T && tx >= 0 && tx < a.T;
+      const bool okd = co < a.Cout && t < a.T, okx = ci < a.Cin && t < a.T && tx >= 0 && tx < a.Tx;
       const float d = dyb[(int64_t)min(co, a.Cout - 1) * a.T + min(t, a.T - 1)];
-      const float v = xb[(int64_t)min(ci, a.Cin - 1) * a.T + min(max(tx, 0), a.T - 1)];
+      const float v = xb[(int64_t)min(ci, a.Cin - 1) * a.Tx + min(max(tx, 0), a.Tx - 1)];
       vd[i] = okd ? d : 0.f;
       vx[i] = okx ? v : 0.f;
     }
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps + tap, acc[r]);
+      if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps_out + a.tap_out + tap, acc[r]);
     }
   }
 }
@@ -108,6 +111,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   WgArgs a;
   a.dy = dy; a.x = x; a.dw = dw;
   a.Cout = Cout; a.Cin = Cin; a.taps = taps; a.dil = dil; a.pad = dil * (taps - 1) / 2; a.B = B; a.T = (int)T;
+  a.xstride = 1; a.xoff = 0; a.Tx = (int)T; a.taps_out = taps; a.tap_out = 0;
   a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
   const int tiles = ((Cin + kWgTile - 1) / kWgTile) * ((Cout + kWgTile - 1) / kWgTile) * taps;
   const int total = B * a.chunks_per_item;
@@ -127,6 +131,40 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
     hipLaunchKernelGGL(conv_bgrad_kernel, dim3((unsigned)Cout), dim3(256), 0, st, dy, db, Cout, B, (int)T);
     DMEL_HIP(hipGetLastError());
   }
+  return DMEL_OK;
+}
+
+// One tap of a stride-s convolution / transposed convolution: dw[(r * Ccols + c) * taps_out + tap_out] (+)= sum_{b,t} rows[b, r, t] *
+// cols[b, c, t * xstride + xoff]; rows (B, Crows, T), cols (B, Ccols, Tx).  The caller zeroes dw once before the taps.
+int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, int Crows, int Ccols, int xstride, int xoff, int64_t T,
+                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t st) {
+  DMEL_CHECK_ARG(rows && cols && dw, "conv_wgrad_strided: NULL argument");
+  DMEL_CHECK_ARG(B > 0 && T > 0 && Tx > 0 && Tx < ((int64_t)1 << 30) && Crows > 0 && Ccols > 0 && xstride > 0 && taps_out > 0 &&
+                     tap_out >= 0 && tap_out < taps_out, "conv_wgrad_strided: bad shape");
+  WgArgs a;
+  a.dy = rows; a.x = cols; a.dw = dw;
+  a.Cout = Crows; a.Cin = Ccols; a.taps = 1; a.dil = 1; a.pad = 0; a.B = B; a.T = (int)T;
+  a.xstride = xstride; a.xoff = xoff; a.Tx = (int)Tx; a.taps_out = taps_out; a.tap_out = tap_out;
+  a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
+  const int tiles = ((Ccols + kWgTile - 1) / kWgTile) * ((Crows + kWgTile - 1) / kWgTile);
+  const int total = B * a.chunks_per_item;
+  int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
+  slices = std::min(slices, 65535);
+  a.slices = slices;
+  a.chunks_per_slice = (total + slices - 1) / slices;
+  dim3 grid((unsigned)((Ccols + kWgTile - 1) / kWgTile), (unsigned)((Crows + kWgTile - 1) / kWgTile), (unsigned)slices);
+  {
+    ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols, 0.0);
+    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, a);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+int launch_conv_bgrad(const float* dy, float* db, int Cout, int B, int64_t T, hipStream_t st) {
+  DMEL_CHECK_ARG(dy && db && Cout > 0 && B > 0 && T > 0 && T < ((int64_t)1 << 31), "conv_bgrad: bad argument");
+  hipLaunchKernelGGL(conv_bgrad_kernel, dim3((unsigned)Cout), dim3(256), 0, st, dy, db, Cout, B, (int)T);
+  DMEL_HIP(hipGetLastError());
   return DMEL_OK;
 }
 

@@ -651,6 +651,10 @@ struct dmel_convnext {
   int64_t grad_floats = 0;
 };
 
+namespace {
+int pack_convnext_T(PackedConv& pw1T, PackedConv& pw2T, const TensorStore& ts, const std::string& p, int C);
+}
+
 extern "C" int dmel_convnext_create(dmel_convnext** out, int dim) {
   DMEL_CHECK_ARG(out && dim > 0, "convnext_create: bad argument");
   auto* m = new dmel_convnext();
@@ -676,14 +680,7 @@ extern "C" int dmel_convnext_finalize(dmel_convnext* m) {
   const int C = m->C;
   DMEL_TRY(build_convnext(m->cx, m->ts, "", C));
   if (m->train) {
-    const HostTensor* w1 = m->ts.need("pwconv1.weight", {4 * C, C});
-    const HostTensor* w2 = m->ts.need("pwconv2.weight", {C, 4 * C});
-    if (!w1 || !w2) return DMEL_EMISSING;
-    PackDesc d;
-    d.mode = EPI_LINEAR; d.nseg = 1; d.C = C; d.seg[0].Cin = 4 * C;          // d u (4C) -> d h1 (C): W1^T
-    DMEL_TRY(pack_conv(m->pw1T, d, [&](int, int row, int cc, int) { return w1->v[(size_t)cc * C + row]; }, [&](int) { return 0.f; }));
-    d.C = 4 * C; d.seg[0].Cin = C;                                           // d v (C) -> d g (4C): W2^T
-    DMEL_TRY(pack_conv(m->pw2T, d, [&](int, int row, int cc, int) { return w2->v[(size_t)cc * 4 * C + row]; }, [&](int) { return 0.f; }));
+    DMEL_TRY(pack_convnext_T(m->pw1T, m->pw2T, m->ts, "", C));
     m->slots.clear();
     int64_t off = 0;
     auto slot = [&](const char* key, int64_t numel) { m->slots.push_back({key, off, numel}); off += numel; };
@@ -712,15 +709,58 @@ extern "C" int dmel_convnext_forward(const dmel_convnext* m, const float* x, flo
 
 namespace {
 struct CxPlan { float *H0, *H1, *U, *G, *V, *DV, *DG, *DH1, *DH0; size_t n, bytes; };
-CxPlan cx_plan(const dmel_convnext* m, int N, int64_t T, void* ws) {
+CxPlan cx_plan_at(Arena& a, size_t n) {
   CxPlan p{};
-  Arena a(ws, (size_t)-1);
-  const size_t n = (size_t)N * m->C * T;
   p.n = n;
   p.H0 = a.take<float>(n); p.H1 = a.take<float>(n); p.U = a.take<float>(4 * n); p.G = a.take<float>(4 * n); p.V = a.take<float>(n);
   p.DV = a.take<float>(n); p.DG = a.take<float>(4 * n); p.DH1 = a.take<float>(n); p.DH0 = a.take<float>(n);
+  return p;
+}
+CxPlan cx_plan(const dmel_convnext* m, int N, int64_t T, void* ws) {
+  Arena a(ws, (size_t)-1);
+  CxPlan p = cx_plan_at(a, (size_t)N * m->C * T);
   p.bytes = align_up(a.off, 256);
   return p;
+}
+struct CxGrads { float *dw_w, *dw_b, *ln_w, *ln_b, *w1, *b1, *w2, *b2, *gamma; };
+
+// firefly.py:383-402 unfused, keeping the pre-norm, normed, pre-GELU, post-GELU and pre-scale tensors for backward
+int convnext_train_fwd(const ConvNeXt& cx, const CxPlan& p, const float* x, float* y, int N, int C, int64_t T, hipStream_t st) {
+  DMEL_TRY(launch_dwconv_ln(x, p.H1, cx.dw_w.as<float>(), cx.dw_b.as<float>(), cx.ln_w.as<float>(), cx.ln_b.as<float>(), N, C, T, st, p.H0));
+  ConvRun a = run_1seg(p.H1, C, T, p.U, 4 * C, T, N);
+  DMEL_TRY(launch_conv(cx.pw1, a, st));
+  DMEL_TRY(launch_gelu_fwd(p.U, p.G, (int64_t)(4 * p.n), st));
+  ConvRun b = run_1seg(p.G, 4 * C, T, p.V, C, T, N);
+  DMEL_TRY(launch_conv(cx.pw2, b, st));
+  return launch_layerscale_res_fwd(x, p.V, cx.gamma.as<float>(), y, N, C, T, st);
+}
+int convnext_bwd(const ConvNeXt& cx, const PackedConv& pw1T, const PackedConv& pw2T, const CxPlan& p, const CxGrads& g, const float* x,
+                 const float* dy, float* dx, int N, int C, int64_t T, hipStream_t st) {
+  DMEL_TRY(launch_layerscale_bwd(dy, p.V, cx.gamma.as<float>(), p.DV, g.gamma, N, C, T, st));          // y = x + gamma * V
+  DMEL_TRY(launch_conv_wgrad(p.G, p.DV, g.w2, g.b2, C, 4 * C, 1, 1, N, T, st));                         // V = pwconv2(G)
+  {
+    ConvRun r = run_1seg(p.DV, C, T, p.DG, 4 * C, T, N);
+    DMEL_TRY(launch_conv(pw2T, r, st));
+  }
+  DMEL_TRY(launch_gelu_bwd(p.DG, p.U, p.DG, (int64_t)(4 * p.n), st));                                   // G = gelu(U); d U overwrites d G
+  DMEL_TRY(launch_conv_wgrad(p.H1, p.DG, g.w1, g.b1, 4 * C, C, 1, 1, N, T, st));                        // U = pwconv1(H1)
+  {
+    ConvRun r = run_1seg(p.DG, 4 * C, T, p.DH1, C, T, N);
+    DMEL_TRY(launch_conv(pw1T, r, st));
+  }
+  // H1 = LayerNorm(H0), H0 = dwconv(x); dx = dy (identity path) + dwconv^T(d H0)
+  DMEL_TRY(launch_ln_bwd(p.DH1, p.H0, cx.ln_w.as<float>(), p.DH0, g.ln_w, g.ln_b, N, C, T, st));
+  return launch_dwconv_bwd(p.DH0, x, cx.dw_w.as<float>(), dy, dx, g.dw_w, g.dw_b, N, C, T, st);
+}
+int pack_convnext_T(PackedConv& pw1T, PackedConv& pw2T, const TensorStore& ts, const std::string& p, int C) {
+  const HostTensor* w1 = ts.need(p + "pwconv1.weight", {4 * C, C});
+  const HostTensor* w2 = ts.need(p + "pwconv2.weight", {C, 4 * C});
+  if (!w1 || !w2) return DMEL_EMISSING;
+  PackDesc d;
+  d.mode = EPI_LINEAR; d.nseg = 1; d.C = C; d.seg[0].Cin = 4 * C;          // d u (4C) -> d h1 (C): W1^T
+  DMEL_TRY(pack_conv(pw1T, d, [&](int, int row, int cc, int) { return w1->v[(size_t)cc * C + row]; }, [&](int) { return 0.f; }));
+  d.C = 4 * C; d.seg[0].Cin = C;                                           // d v (C) -> d g (4C): W2^T
+  return pack_conv(pw2T, d, [&](int, int row, int cc, int) { return w2->v[(size_t)cc * 4 * C + row]; }, [&](int) { return 0.f; });
 }
 }  // namespace
 
@@ -738,7 +778,6 @@ extern "C" int dmel_convnext_grad_slot(const dmel_convnext* m, const char* key, 
   return DMEL_EINVAL;
 }
 
-// firefly.py:383-402 unfused, keeping the pre-norm, normed, pre-GELU, post-GELU and pre-scale tensors for backward
 extern "C" int dmel_convnext_forward_train(const dmel_convnext* m, const float* x, float* y, int N, int64_t T, void* workspace,
                                            size_t workspace_bytes, void* stream) {
   DMEL_CHECK_ARG(m && x && y && workspace, "convnext_forward_train: NULL argument");
@@ -746,16 +785,7 @@ extern "C" int dmel_convnext_forward_train(const dmel_convnext* m, const float* 
   DMEL_CHECK_ARG(N > 0 && T > 0, "convnext_forward_train: bad shape");
   const CxPlan p = cx_plan(m, N, T, workspace);
   DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "convnext_forward_train: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
-  hipStream_t st = (hipStream_t)stream;
-  const int C = m->C;
-  const ConvNeXt& cx = m->cx;
-  DMEL_TRY(launch_dwconv_ln(x, p.H1, cx.dw_w.as<float>(), cx.dw_b.as<float>(), cx.ln_w.as<float>(), cx.ln_b.as<float>(), N, C, T, st, p.H0));
-  ConvRun a = run_1seg(p.H1, C, T, p.U, 4 * C, T, N);
-  DMEL_TRY(launch_conv(cx.pw1, a, st));
-  DMEL_TRY(launch_gelu_fwd(p.U, p.G, (int64_t)(4 * p.n), st));
-  ConvRun b = run_1seg(p.G, 4 * C, T, p.V, C, T, N);
-  DMEL_TRY(launch_conv(cx.pw2, b, st));
-  return launch_layerscale_res_fwd(x, p.V, cx.gamma.as<float>(), y, N, C, T, st);
+  return convnext_train_fwd(m->cx, p, x, y, N, m->C, T, (hipStream_t)stream);
 }
 
 extern "C" int dmel_convnext_backward(const dmel_convnext* m, const float* x, const float* dy, float* dx, float* grads, int N, int64_t T,
@@ -765,33 +795,14 @@ extern "C" int dmel_convnext_backward(const dmel_convnext* m, const float* x, co
   DMEL_CHECK_ARG(N > 0 && T > 0, "convnext_backward: bad shape");
   const CxPlan p = cx_plan(m, N, T, workspace);
   DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "convnext_backward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
-  hipStream_t st = (hipStream_t)stream;
-  const int C = m->C;
-  const ConvNeXt& cx = m->cx;
   auto G = [&](const char* key) -> float* {
     for (const auto& s : m->slots)
       if (s.key == key) return grads + s.offset;
     return nullptr;
   };
-  // y = x + gamma * V
-  DMEL_TRY(launch_layerscale_bwd(dy, p.V, cx.gamma.as<float>(), p.DV, G("gamma"), N, C, T, st));
-  // V = pwconv2(G)
-  DMEL_TRY(launch_conv_wgrad(p.G, p.DV, G("pwconv2.weight"), G("pwconv2.bias"), C, 4 * C, 1, 1, N, T, st));
-  {
-    ConvRun r = run_1seg(p.DV, C, T, p.DG, 4 * C, T, N);
-    DMEL_TRY(launch_conv(m->pw2T, r, st));
-  }
-  // G = gelu(U)   (d U overwrites d G)
-  DMEL_TRY(launch_gelu_bwd(p.DG, p.U, p.DG, (int64_t)(4 * p.n), st));
-  // U = pwconv1(H1)
-  DMEL_TRY(launch_conv_wgrad(p.H1, p.DG, G("pwconv1.weight"), G("pwconv1.bias"), 4 * C, C, 1, 1, N, T, st));
-  {
-    ConvRun r = run_1seg(p.DG, 4 * C, T, p.DH1, C, T, N);
-    DMEL_TRY(launch_conv(m->pw1T, r, st));
-  }
-  // H1 = LayerNorm(H0), H0 = dwconv(x); dx = dy (identity path) + dwconv^T(d H0)
-  DMEL_TRY(launch_ln_bwd(p.DH1, p.H0, cx.ln_w.as<float>(), p.DH0, G("norm.weight"), G("norm.bias"), N, C, T, st));
-  return launch_dwconv_bwd(p.DH0, x, cx.dw_w.as<float>(), dy, dx, G("dwconv.weight"), G("dwconv.bias"), N, C, T, st);
+  CxGrads g{G("dwconv.weight"), G("dwconv.bias"), G("norm.weight"), G("norm.bias"), G("pwconv1.weight"), G("pwconv1.bias"),
+            G("pwconv2.weight"), G("pwconv2.bias"), G("gamma")};
+  return convnext_bwd(m->cx, m->pw1T, m->pw2T, p, g, x, dy, dx, N, m->C, T, (hipStream_t)stream);
 }
 
 struct dmel_quantizer {
@@ -804,6 +815,18 @@ struct dmel_quantizer {
   std::vector<PackedConv> down, up;
   std::vector<ConvNeXt> down_cx, up_cx;
   DevBuf w_in, b_in, w_out, b_out;
+  // training path
+  bool train = false, train_ready = false;
+  std::vector<PackedConv> down_dx, up_dx;                      // backward-data images of the k2s2 conv / transposed conv
+  std::vector<PackedConv> down_pw1T, down_pw2T, up_pw1T, up_pw2T;
+  struct GradSlot { std::string key; int64_t offset, numel; };
+  std::vector<GradSlot> slots;
+  int64_t grad_floats = 0;
+  int64_t slot_of(const std::string& key) const {
+    for (const auto& s : slots)
+      if (s.key == key) return s.offset;
+    return -1;
+  }
 };
 
 extern "C" int dmel_quantizer_create(dmel_quantizer** out, int input_dim, int n_groups, const int* levels, int n_levels,
@@ -879,8 +902,71 @@ extern "C" int dmel_quantizer_finalize(dmel_quantizer* q) {
   }
   DMEL_TRY(upload_vec(q->w_in, wi)); DMEL_TRY(upload_vec(q->b_in, bi));
   DMEL_TRY(upload_vec(q->w_out, wo)); DMEL_TRY(upload_vec(q->b_out, bo));
+  if (q->train) {
+    q->down_dx.clear(); q->up_dx.clear(); q->down_pw1T.clear(); q->down_pw2T.clear(); q->up_pw1T.clear(); q->up_pw2T.clear();
+    q->down_dx.resize(q->nf); q->up_dx.resize(q->nf);
+    q->down_pw1T.resize(q->nf); q->down_pw2T.resize(q->nf); q->up_pw1T.resize(q->nf); q->up_pw2T.resize(q->nf);
+    q->slots.clear();
+    int64_t off = 0;
+    auto slot = [&](const std::string& key, int64_t numel) { q->slots.push_back({key, off, numel}); off += numel; };
+    const char* cxk[9] = {"dwconv.weight", "dwconv.bias", "norm.weight", "norm.bias", "pwconv1.weight", "pwconv1.bias", "pwconv2.weight",
+                          "pwconv2.bias", "gamma"};
+    const int64_t cxn[9] = {(int64_t)C * 7, C, C, C, (int64_t)4 * C * C, 4 * C, (int64_t)4 * C * C, C, C};
+    for (int i = 0; i < q->nf; ++i) {
+      const std::string pd = "downsample." + std::to_string(i) + ".", pu = "upsample." + std::to_string(i) + ".";
+      const HostTensor* wd = q->ts.need(pd + "0.weight", {C, C, 2});
+      const HostTensor* wu = q->ts.need(pu + "0.weight", {C, C, 2});
+      if (!wd || !wu) return DMEL_EMISSING;
+      {  // d x[ci, 2q + k] = sum_co W[co, ci, k] d y[co, q]: a k2s2 transposed conv (phase-major rows)
+        PackDesc d;
+        d.mode = EPI_LINEAR; d.nseg = 1; d.C = C; d.phases = 2; d.seg[0].Cin = C;
+        DMEL_TRY(pack_conv(q->down_dx[i], d,
+                           [&](int, int row, int cc, int) { int ph = row / C, ci = row % C; return wd->v[((size_t)cc * C + ci) * 2 + ph]; },
+                           [&](int) { return 0.f; }));
+      }
+      {  // d x[ci, q] = sum_{co, k} W[ci, co, k] d y[co, 2q + k]: a k2s2 conv (two strided 1-tap segments)
+        PackDesc d;
+        d.mode = EPI_LINEAR; d.nseg = 2; d.C = C;
+        for (int sgi = 0; sgi < 2; ++sgi) { d.seg[sgi].Cin = C; d.seg[sgi].tstride = 2; d.seg[sgi].toff = sgi; }
+        DMEL_TRY(pack_conv(q->up_dx[i], d, [&](int sg, int row, int cc, int) { return wu->v[((size_t)row * C + cc) * 2 + sg]; },
+                           [&](int) { return 0.f; }));
+      }
+      DMEL_TRY(pack_convnext_T(q->down_pw1T[i], q->down_pw2T[i], q->ts, pd + "1.", C));
+      DMEL_TRY(pack_convnext_T(q->up_pw1T[i], q->up_pw2T[i], q->ts, pu + "1.", C));
+      slot(pd + "0.weight", (int64_t)C * C * 2); slot(pd + "0.bias", C);
+      for (int k = 0; k < 9; ++k) slot(pd + "1." + cxk[k], cxn[k]);
+      slot(pu + "0.weight", (int64_t)C * C * 2); slot(pu + "0.bias", C);
+      for (int k = 0; k < 9; ++k) slot(pu + "1." + cxk[k], cxn[k]);
+    }
+    // FSQ parameter gradients come out in the packed (G, ...) layouts: group g's tensor is the g-th block of each region
+    const int64_t o_wi = off; off += (int64_t)G * D * C;
+    const int64_t o_bi = off; off += (int64_t)G * D;
+    const int64_t o_wo = off; off += (int64_t)G * C * D;
+    const int64_t o_bo = off; off += (int64_t)G * C;
+    for (int g = 0; g < G; ++g) {
+      const std::string p = "residual_fsq.rvqs." + std::to_string(g) + ".";
+      q->slots.push_back({p + "project_in.weight", o_wi + (int64_t)g * D * C, (int64_t)D * C});
+      q->slots.push_back({p + "project_in.bias", o_bi + (int64_t)g * D, D});
+      q->slots.push_back({p + "project_out.weight", o_wo + (int64_t)g * C * D, (int64_t)C * D});
+      q->slots.push_back({p + "project_out.bias", o_bo + (int64_t)g * C, C});
+    }
+    q->slots.push_back({"#fsq.w_in", o_wi, (int64_t)G * D * C});
+    q->slots.push_back({"#fsq.b_in", o_bi, (int64_t)G * D});
+    q->slots.push_back({"#fsq.w_out", o_wo, (int64_t)G * C * D});
+    q->slots.push_back({"#fsq.b_out", o_bo, (int64_t)G * C});
+    q->grad_floats = off;
+    q->train_ready = true;
+  }
   q->ts.t.clear();
   q->ready = true;
+  return DMEL_OK;
+}
+
+extern "C" int dmel_quantizer_enable_training(dmel_quantizer* q, int on) {
+  DMEL_CHECK_ARG(q, "NULL handle");
+  q->train = on != 0;
+  q->ready = false;
+  q->train_ready = false;
   return DMEL_OK;
 }
 
@@ -955,6 +1041,183 @@ extern "C" int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids
     DMEL_TRY(run_convnext(q->up_cx[j], o, o, h1, h2, N, C, Tn, st));
     cur = o;
     Tc = Tn;
+  }
+  return DMEL_OK;
+}
+
+// ---- quantiser training path: DownsampleFiniteScalarQuantize.forward (dowmsample_fsq.py:86-122) and its backward ----------
+namespace {
+struct QStage { float* in; float* conv; CxPlan cx; int64_t Tin, Tout; };      // input of the (transposed) conv, its output = ConvNeXt input
+struct QPlan {
+  QStage down[4], up[4];
+  float *lat, *fsq_out, *ga, *gb, *scratch;
+  int32_t* ids;
+  int64_t T4;
+  size_t bytes;
+};
+QPlan q_plan(const dmel_quantizer* q, int B, int64_t T, void* ws) {
+  QPlan p{};
+  Arena a(ws, (size_t)-1);
+  const size_t NC = (size_t)B * q->G * q->Cg;
+  int64_t Tc = T;
+  for (int i = 0; i < q->nf; ++i) {
+    const int64_t Tn = Tc / 2;
+    p.down[i].Tin = Tc; p.down[i].Tout = Tn;
+    p.down[i].in = i == 0 ? nullptr : a.take<float>(NC * Tc);     // stage 0 reads the caller's z
+    p.down[i].conv = a.take<float>(NC * Tn);
+    p.down[i].cx = cx_plan_at(a, NC * Tn);
+    Tc = Tn;
+  }
+  p.T4 = Tc;
+  p.lat = a.take<float>(NC * Tc);
+  p.ids = a.take<int32_t>((size_t)B * q->G * Tc);
+  p.fsq_out = a.take<float>(NC * Tc);
+  p.scratch = a.take<float>((size_t)2 * B * q->G * Tc * q->D);
+  for (int j = 0; j < q->nf; ++j) {
+    const int64_t Tn = Tc * 2;
+    p.up[j].Tin = Tc; p.up[j].Tout = Tn;
+    p.up[j].in = j == 0 ? p.fsq_out : a.take<float>(NC * Tc);
+    p.up[j].conv = a.take<float>(NC * Tn);
+    p.up[j].cx = cx_plan_at(a, NC * Tn);
+    Tc = Tn;
+  }
+  p.ga = a.take<float>(NC * T);
+  p.gb = a.take<float>(NC * T);
+  p.bytes = align_up(a.off, 256);
+  return p;
+}
+CxGrads cx_grads(const dmel_quantizer* q, float* grads, const std::string& p) {
+  auto G = [&](const char* k) { return grads + q->slot_of(p + k); };
+  return CxGrads{G("dwconv.weight"), G("dwconv.bias"), G("norm.weight"), G("norm.bias"), G("pwconv1.weight"), G("pwconv1.bias"),
+                 G("pwconv2.weight"), G("pwconv2.bias"), G("gamma")};
+}
+}  // namespace
+
+extern "C" size_t dmel_quantizer_train_workspace_bytes(const dmel_quantizer* q, int B, int64_t T) {
+  if (!q || B <= 0 || T <= 0) return 0;
+  return q_plan(q, B, T, nullptr).bytes;
+}
+extern "C" int64_t dmel_quantizer_grad_floats(const dmel_quantizer* q) { return q && q->train_ready ? q->grad_floats : 0; }
+extern "C" int dmel_quantizer_grad_slot(const dmel_quantizer* q, const char* key, int64_t* offset, int64_t* numel) {
+  DMEL_CHECK_ARG(q && key && offset && numel, "quantizer_grad_slot: NULL argument");
+  if (!q->train_ready) { set_error("quantizer_grad_slot: training was not enabled before finalize"); return DMEL_EMISSING; }
+  for (const auto& s : q->slots)
+    if (s.key == key) { *offset = s.offset; *numel = s.numel; return DMEL_OK; }
+  set_error("quantizer_grad_slot: '%s' is not a trained parameter of this quantiser", key);
+  return DMEL_EINVAL;
+}
+
+// z (B*G, Cg, T) -> zq (B*G, Cg, T) [= (B, G*Cg, T)], ids (B, G, T4), latents (B*G, Cg, T4); zq is zero-padded from 2^nf * T4 to T
+// (left = diff / 2) exactly as dowmsample_fsq.py:113-120.
+extern "C" int dmel_quantizer_forward_train(const dmel_quantizer* q, const float* z, float* zq, int32_t* ids, float* latents, int B,
+                                            int64_t T, void* workspace, size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(q && z && zq && workspace, "quantizer_forward_train: NULL argument");
+  if (!q->ready || !q->train_ready) { set_error("quantizer_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
+  const QPlan p = q_plan(q, B, T, workspace);
+  DMEL_CHECK_ARG(B > 0 && p.T4 > 0, "quantizer_forward_train: sequence too short for the downsampling (T=%lld)", (long long)T);
+  DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "quantizer_forward_train: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const int N = B * q->G, C = q->Cg;
+  const size_t NC = (size_t)N * C;
+  const float* cur = z;
+  for (int i = 0; i < q->nf; ++i) {
+    const QStage& sgq = p.down[i];
+    ConvRun r;
+    for (int s = 0; s < 2; ++s) { r.seg[s].x = cur; r.seg[s].bstride = (int64_t)C * sgq.Tin; r.seg[s].cstride = sgq.Tin; r.seg[s].Tin = sgq.Tin; }
+    r.B = N; r.Tcols = sgq.Tout; r.y = sgq.conv; r.y_bs = (int64_t)C * sgq.Tout; r.y_cs = sgq.Tout; r.Tout = sgq.Tout;
+    DMEL_TRY(launch_conv(q->down[i], r, st));
+    float* o = (i == q->nf - 1) ? p.lat : p.down[i + 1].in;
+    DMEL_TRY(convnext_train_fwd(q->down_cx[i], sgq.cx, sgq.conv, o, N, C, sgq.Tout, st));
+    cur = o;
+  }
+  DMEL_TRY(launch_fsq_encode(p.lat, q->w_in.as<float>(), q->b_in.as<float>(), p.ids, nullptr, q->fk, B, q->G, C, p.T4, st));
+  DMEL_TRY(launch_fsq_decode(p.ids, q->w_out.as<float>(), q->b_out.as<float>(), p.fsq_out, q->fk, B, q->G, C, p.T4, st));
+  if (ids) DMEL_HIP(hipMemcpyAsync(ids, p.ids, (size_t)B * q->G * p.T4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  if (latents) DMEL_HIP(hipMemcpyAsync(latents, p.lat, NC * p.T4 * sizeof(float), hipMemcpyDeviceToDevice, st));
+  cur = p.fsq_out;
+  for (int j = 0; j < q->nf; ++j) {
+    const QStage& sgq = p.up[j];
+    ConvRun r = run_1seg(cur, C, sgq.Tin, sgq.conv, C, sgq.Tout, N);
+    r.Tcols = sgq.Tin; r.out_tstride = 2; r.Tout = sgq.Tout;
+    DMEL_TRY(launch_conv(q->up[j], r, st));
+    float* o = (j == q->nf - 1) ? p.ga : p.up[j + 1].in;
+    DMEL_TRY(convnext_train_fwd(q->up_cx[j], sgq.cx, sgq.conv, o, N, C, sgq.Tout, st));
+    cur = o;
+  }
+  const int64_t Tfull = p.up[q->nf - 1].Tout, diff = T - Tfull, left = diff / 2;
+  if (diff == 0) {
+    DMEL_HIP(hipMemcpyAsync(zq, p.ga, NC * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    DMEL_HIP(hipMemsetAsync(zq, 0, NC * T * sizeof(float), st));
+    DMEL_HIP(hipMemcpy2DAsync(zq + left, (size_t)T * sizeof(float), p.ga, (size_t)Tfull * sizeof(float), (size_t)Tfull * sizeof(float), NC,
+                              hipMemcpyDeviceToDevice, st));
+  }
+  return DMEL_OK;
+}
+
+extern "C" int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, const float* dzq, float* dz, float* grads, int B, int64_t T,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(q && z && dzq && dz && grads && workspace, "quantizer_backward: NULL argument");
+  if (!q->ready || !q->train_ready) { set_error("quantizer_backward: enable_training + finalize first"); return DMEL_EMISSING; }
+  const QPlan p = q_plan(q, B, T, workspace);
+  DMEL_CHECK_ARG(B > 0 && p.T4 > 0 && workspace_bytes >= p.bytes, "quantizer_backward: bad shape or workspace");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = B * q->G, C = q->Cg;
+  const size_t NC = (size_t)N * C;
+  const int64_t Tfull = p.up[q->nf - 1].Tout, diff = T - Tfull, left = diff / 2;
+  // un-pad: gradient of the cropped region only
+  float* g = p.gb;
+  if (diff == 0) {
+    DMEL_HIP(hipMemcpyAsync(g, dzq, NC * T * sizeof(float), hipMemcpyDeviceToDevice, st));
+  } else {
+    DMEL_HIP(hipMemcpy2DAsync(g, (size_t)Tfull * sizeof(float), dzq + left, (size_t)T * sizeof(float), (size_t)Tfull * sizeof(float), NC,
+                              hipMemcpyDeviceToDevice, st));
+  }
+  float* other = p.ga;
+  for (int j = q->nf - 1; j >= 0; --j) {      // upsample.{j}: ConvTranspose1d(k2, s2) -> ConvNeXtBlock
+    const QStage& sgq = p.up[j];
+    const std::string pu = "upsample." + std::to_string(j) + ".";
+    DMEL_TRY(convnext_bwd(q->up_cx[j], q->up_pw1T[j], q->up_pw2T[j], sgq.cx, cx_grads(q, grads, pu + "1."), sgq.conv, g, other, N, C,
+                          sgq.Tout, st));
+    std::swap(g, other);                       // g = d (transposed conv output), length Tout
+    float* dw = grads + q->slot_of(pu + "0.weight");
+    DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)C * C * 2 * sizeof(float), st));
+    for (int k = 0; k < 2; ++k)                // d W[ci, co, k] = sum x[ci, q] d y[co, 2q + k]
+      DMEL_TRY(launch_conv_wgrad_strided(sgq.in, g, dw, C, C, 2, k, sgq.Tin, sgq.Tout, 2, k, N, st));
+    DMEL_TRY(launch_conv_bgrad(g, grads + q->slot_of(pu + "0.bias"), C, N, sgq.Tout, st));
+    {
+      ConvRun r;
+      for (int s = 0; s < 2; ++s) { r.seg[s].x = g; r.seg[s].bstride = (int64_t)C * sgq.Tout; r.seg[s].cstride = sgq.Tout; r.seg[s].Tin = sgq.Tout; }
+      r.B = N; r.Tcols = sgq.Tin; r.y = other; r.y_bs = (int64_t)C * sgq.Tin; r.y_cs = sgq.Tin; r.Tout = sgq.Tin;
+      DMEL_TRY(launch_conv(q->up_dx[j], r, st));
+    }
+    std::swap(g, other);                       // g = d (stage input), length Tin
+  }
+  // FSQ (straight-through)
+  DMEL_TRY(launch_fsq_backward(p.lat, g, q->w_in.as<float>(), q->b_in.as<float>(), q->w_out.as<float>(), other,
+                               grads + q->slot_of("#fsq.w_in"), grads + q->slot_of("#fsq.b_in"), grads + q->slot_of("#fsq.w_out"),
+                               grads + q->slot_of("#fsq.b_out"), p.scratch, q->fk, B, q->G, C, p.T4, st));
+  std::swap(g, other);
+  for (int i = q->nf - 1; i >= 0; --i) {      // downsample.{i}: Conv1d(k2, s2) -> ConvNeXtBlock
+    const QStage& sgq = p.down[i];
+    const std::string pd = "downsample." + std::to_string(i) + ".";
+    DMEL_TRY(convnext_bwd(q->down_cx[i], q->down_pw1T[i], q->down_pw2T[i], sgq.cx, cx_grads(q, grads, pd + "1."), sgq.conv, g, other, N, C,
+                          sgq.Tout, st));
+    std::swap(g, other);                       // g = d (conv output), length Tout
+    const float* xin = i == 0 ? z : sgq.in;
+    float* dw = grads + q->slot_of(pd + "0.weight");
+    DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)C * C * 2 * sizeof(float), st));
+    for (int k = 0; k < 2; ++k)                // d W[co, ci, k] = sum d y[co, q] x[ci, 2q + k]
+      DMEL_TRY(launch_conv_wgrad_strided(g, xin, dw, C, C, 2, k, sgq.Tout, sgq.Tin, 2, k, N, st));
+    DMEL_TRY(launch_conv_bgrad(g, grads + q->slot_of(pd + "0.bias"), C, N, sgq.Tout, st));
+    float* dst = i == 0 ? dz : other;
+    if (sgq.Tin != 2 * sgq.Tout) DMEL_HIP(hipMemsetAsync(dst, 0, NC * sgq.Tin * sizeof(float), st));   // odd length: the last sample is unused
+    {
+      ConvRun r = run_1seg(g, C, sgq.Tout, dst, C, sgq.Tin, N);
+      r.Tcols = sgq.Tout; r.out_tstride = 2; r.Tout = sgq.Tin;
+      DMEL_TRY(launch_conv(q->down_dx[i], r, st));
+    }
+    if (i > 0) std::swap(g, other);
   }
   return DMEL_OK;
 }

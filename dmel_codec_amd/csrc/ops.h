@@ -16,6 +16,11 @@ int launch_fsq_encode(const float* z, const float* w_in, const float* b_in, int3
                       const FsqConst& k, int B, int G, int C, int64_t T4, hipStream_t s);
 int launch_fsq_decode(const int32_t* ids, const float* w_out, const float* b_out, float* z, const FsqConst& k, int B,
                       int G, int C, int64_t T4, hipStream_t s);
+// FSQ straight-through backward: dx (B*G, C, T4) from dout (same layout) and the saved FSQ input x; parameter gradients in the
+// handle's packed layouts (w_in (G,D,C), b_in (G,D), w_out (G,C,D), b_out (G,C)); scratch >= 2*B*G*T4*D floats
+int launch_fsq_backward(const float* x, const float* dout, const float* w_in, const float* b_in, const float* w_out, float* dx,
+                        float* dw_in, float* db_in, float* dw_out, float* db_out, float* scratch, const FsqConst& k, int B, int G, int C,
+                        int64_t T4, hipStream_t s);
 // h0 (nullable): also store the pre-norm depthwise-conv output (N, C, T) -- the training path keeps it for the LayerNorm backward
 int launch_dwconv_ln(const float* x, float* y, const float* dw_w, const float* dw_b, const float* ln_w, const float* ln_b,
                      int N, int C, int64_t T, hipStream_t s, float* h0 = nullptr);
@@ -52,5 +57,9 @@ int launch_dwconv_bwd(const float* dh0, const float* x, const float* dw_w, const
 // dw (Cout, Cin, taps) = sum_{b,t} dy[b,co,t] * x[b,ci,t + k*dil - pad], pad = dil*(taps-1)/2; db (Cout) nullable.  Overwrites.
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int Cout, int Cin, int taps, int dil, int B, int64_t T,
                       hipStream_t s);
+// one tap of a strided (transposed) conv: dw[(r*Ccols + c)*taps_out + tap_out] += sum_{b,t} rows[b,r,t] * cols[b,c,t*xstride + xoff]
+int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, int Crows, int Ccols, int xstride, int xoff, int64_t T,
+                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t s);
+int launch_conv_bgrad(const float* dy, float* db, int Cout, int B, int64_t T, hipStream_t s);
 
 }  // namespace dmel

@@ -141,6 +141,125 @@ __global__ __launch_bounds__(256) void fsq_decode_kernel(const int32_t* __restri
   z[i] = acc + b_out[g * C + c];
 }
 
+// ---- FSQ backward (straight-through estimator) -----------------------------------------------------------------------------
+// forward (vector_quantize_pytorch FSQ.forward, restated): z3 = W_in x + b_in; [zz = bound(z3)]; b2 = bound(zz);
+// code = round_ste(b2) / half_width; out = W_out code + b_out.  round_ste passes the gradient through unchanged, so
+//   d b2 = d code / half_width;  d zz = d b2 * half_l (1 - tanh^2(zz + shift));  d z3 = the same factor once more when pre-bounded.
+// Point kernel: one thread per (b, g, l): d x (70 channel rows) plus the per-point d z3 and code for the parameter kernel.
+__global__ __launch_bounds__(256) void fsq_bwd_point_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                            const float* __restrict__ w_in, const float* __restrict__ b_in,
+                                                            const float* __restrict__ w_out, float* __restrict__ dx,
+                                                            float* __restrict__ dz3s, float* __restrict__ codes, FsqConst k, int B, int G,
+                                                            int C, int64_t T4) {
+  const int64_t total = (int64_t)B * G * T4;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int64_t l = i % T4;
+  const int g = (int)((i / T4) % G);
+  const int b = (int)(i / (T4 * G));
+  const int64_t row0 = ((int64_t)(b * G + g) * C) * T4 + l;
+  float z3[4], dcode[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { z3[j] = 0.f; dcode[j] = 0.f; }
+  for (int c = 0; c < C; ++c) {
+    const float v = x[row0 + (int64_t)c * T4], d = dout[row0 + (int64_t)c * T4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < k.n_levels) {
+        z3[j] = fmaf(w_in[((int64_t)g * k.n_levels + j) * C + c], v, z3[j]);
+        dcode[j] = fmaf(w_out[((int64_t)g * C + c) * k.n_levels + j], d, dcode[j]);
+      }
+  }
+  float dz3[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    dz3[j] = 0.f;
+    if (j < k.n_levels) {
+      const float z = z3[j] + b_in[g * k.n_levels + j];
+      float zz = z, f0 = 1.f;
+      if (k.prebound) {
+        const float t0 = tanhf(z + k.shift[j]);
+        zz = t0 * k.half_l[j] - k.offset[j];
+        f0 = k.half_l[j] * (1.f - t0 * t0);
+      }
+      const float t1 = tanhf(zz + k.shift[j]);
+      const float b2 = t1 * k.half_l[j] - k.offset[j];
+      const float code = rintf(b2) / (float)k.half_width[j];
+      dz3[j] = dcode[j] / (float)k.half_width[j] * k.half_l[j] * (1.f - t1 * t1) * f0;
+      const int64_t o = (((int64_t)g * B + b) * T4 + l) * k.n_levels + j;
+      dz3s[o] = dz3[j];
+      codes[o] = code;
+    }
+  }
+  for (int c = 0; c < C; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < k.n_levels) acc = fmaf(w_in[((int64_t)g * k.n_levels + j) * C + c], dz3[j], acc);
+    dx[row0 + (int64_t)c * T4] = acc;
+  }
+}
+
+// grid (C, G): d W_out[g][c][:], d b_out[g][c], d W_in[g][:][c] (and d b_in[g][:] from the c == 0 workgroup), reduced over (b, l)
+__global__ __launch_bounds__(256) void fsq_bwd_param_kernel(const float* __restrict__ x, const float* __restrict__ dout,
+                                                            const float* __restrict__ dz3s, const float* __restrict__ codes,
+                                                            float* __restrict__ dw_in, float* __restrict__ db_in, float* __restrict__ dw_out,
+                                                            float* __restrict__ db_out, int D, int B, int G, int C, int64_t T4) {
+  __shared__ float part[13][4];
+  const int c = blockIdx.x, g = blockIdx.y;
+  float acc[13];        // [0..3] dW_out, [4] db_out, [5..8] dW_in, [9..12] db_in
+#pragma unroll
+  for (int q = 0; q < 13; ++q) acc[q] = 0.f;
+  const int64_t n_pts = (int64_t)B * T4;
+  for (int64_t n = threadIdx.x; n < n_pts; n += 256) {
+    const int b = (int)(n / T4);
+    const int64_t l = n - (int64_t)b * T4;
+    const int64_t e = ((int64_t)(b * G + g) * C + c) * T4 + l;
+    const float d = dout[e], v = x[e];
+    const int64_t o = (((int64_t)g * B + b) * T4 + l) * D;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (j < D) {
+        acc[j] = fmaf(d, codes[o + j], acc[j]);
+        acc[5 + j] = fmaf(dz3s[o + j], v, acc[5 + j]);
+        acc[9 + j] += dz3s[o + j];
+      }
+    acc[4] += d;
+  }
+#pragma unroll
+  for (int q = 0; q < 13; ++q) {
+    float sacc = acc[q];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[q][threadIdx.x >> 6] = sacc;
+  }
+  __syncthreads();
+  if (threadIdx.x < 13) {
+    const int q = threadIdx.x;
+    const float v = part[q][0] + part[q][1] + part[q][2] + part[q][3];
+    if (q < 4) { if (q < D) dw_out[((int64_t)g * C + c) * D + q] = v; }
+    else if (q == 4) db_out[g * C + c] = v;
+    else if (q < 9) { if (q - 5 < D) dw_in[((int64_t)g * D + (q - 5)) * C + c] = v; }
+    else if (c == 0 && q - 9 < D) db_in[g * D + (q - 9)] = v;
+  }
+}
+
+// dx (B*G, C, T4); parameter gradients in the packed (G, ...) layouts of the handle's FSQ buffers; scratch: 2 * G*B*T4*D floats
+int launch_fsq_backward(const float* x, const float* dout, const float* w_in, const float* b_in, const float* w_out, float* dx,
+                        float* dw_in, float* db_in, float* dw_out, float* db_out, float* scratch, const FsqConst& k, int B, int G, int C,
+                        int64_t T4, hipStream_t s) {
+  const int64_t total = (int64_t)B * G * T4;
+  float* dz3s = scratch;
+  float* codes = scratch + total * k.n_levels;
+  hipLaunchKernelGGL(fsq_bwd_point_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, dout, w_in, b_in, w_out, dx, dz3s,
+                     codes, k, B, G, C, T4);
+  DMEL_HIP(hipGetLastError());
+  hipLaunchKernelGGL(fsq_bwd_param_kernel, dim3((unsigned)C, (unsigned)G), dim3(256), 0, s, x, dout, dz3s, codes, dw_in, db_in, dw_out,
+                     db_out, k.n_levels, B, G, C, T4);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
 int make_fsq_const(FsqConst& k, const int* levels, int n, int prebound) {
   DMEL_CHECK_ARG(n >= 1 && n <= 4, "FSQ: 1..4 levels supported, got %d", n);
   k.n_levels = n;

@@ -42,6 +42,51 @@ class _GroupedResidualFSQParams(nn.Module):
         self.rvqs = nn.ModuleList([_ResidualFSQParams(dim // groups, len(levels)) for _ in range(groups)])
 
 
+class _QuantizerTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, z, *params):
+        L = _lib.lib()
+        G = module.groups
+        B, T = z.shape[0] // G, z.shape[2]
+        T4 = T // math.prod(module.downsample_factor)
+        zq = torch.empty_like(z)
+        ids = torch.empty(B, G, T4, dtype=torch.int32, device=z.device)
+        lat = torch.empty(z.shape[0], z.shape[1], T4, dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            h = module.native()
+            ws = torch.empty(L.dmel_quantizer_train_workspace_bytes(h, B, T), dtype=torch.uint8, device=z.device)
+            _lib.check(L.dmel_quantizer_forward_train(h, z.data_ptr(), zq.data_ptr(), ids.data_ptr(), lat.data_ptr(), B, T, ws.data_ptr(),
+                                                      ws.numel(), _lib.stream_ptr()), "quantizer_forward_train")
+        ctx.module, ctx.handle, ctx.ws = module, h, ws
+        ctx.save_for_backward(z)
+        ctx.mark_non_differentiable(ids, lat)
+        return zq, ids, lat
+
+    @staticmethod
+    def backward(ctx, dzq, _dids, _dlat):
+        module, h, ws = ctx.module, ctx.handle, ctx.ws
+        (z,) = ctx.saved_tensors
+        if module._handle != h:
+            raise RuntimeError("quantiser parameters changed between forward and backward")
+        L = _lib.lib()
+        B, T = z.shape[0] // module.groups, z.shape[2]
+        dzq = dzq.float().contiguous()
+        dz = torch.empty_like(z)
+        with torch.cuda.device(z.device):
+            flat = torch.empty(L.dmel_quantizer_grad_floats(h), dtype=torch.float32, device=z.device)
+            _lib.check(L.dmel_quantizer_backward(h, z.data_ptr(), dzq.data_ptr(), dz.data_ptr(), flat.data_ptr(), B, T, ws.data_ptr(),
+                                                 ws.numel(), _lib.stream_ptr()), "quantizer_backward")
+        grads = []
+        off, num = C.c_int64(), C.c_int64()
+        for (key, prm), need in zip(module.named_parameters(), ctx.needs_input_grad[2:]):
+            if not need:
+                grads.append(None)
+                continue
+            _lib.check(L.dmel_quantizer_grad_slot(h, key.encode(), C.byref(off), C.byref(num)), "quantizer_grad_slot")
+            grads.append(flat[off.value:off.value + num.value].view(prm.shape))
+        return (None, dz if ctx.needs_input_grad[1] else None, *grads)
+
+
 class DownsampleFiniteScalarQuantize(NativeModule):
     """dowmsample_fsq.py:19-147.  fsq_prebound (extension): whether ResidualFSQ.forward bounds its input before the
     first quantiser (newer vector_quantize_pytorch releases do) -- default True."""
@@ -91,6 +136,7 @@ class DownsampleFiniteScalarQuantize(NativeModule):
         _lib.check(_lib.lib().dmel_quantizer_create(C.byref(h), self.input_dim, self.groups, lv, len(self.levels), fs,
                                                     len(self.downsample_factor), int(self.fsq_prebound)),
                    "quantizer_create")
+        self._create_native_train(h)
         return h.value
 
     @torch.no_grad()
@@ -135,5 +181,22 @@ class DownsampleFiniteScalarQuantize(NativeModule):
                                                _lib.stream_ptr()), "quantizer_decode")
         return z
 
+    def _create_native_train(self, h):
+        if getattr(self, "_want_train", False):
+            _lib.check(_lib.lib().dmel_quantizer_enable_training(h, 1), "quantizer_enable_training")
+
     def forward(self, z) -> FSQResult:
-        raise NotImplementedError("the training-time forward (straight-through FSQ) is SURVEY.md 8f rank 1, not built yet")
+        """Training-time forward (dowmsample_fsq.py:86-122): z (B*G, C, T) -> FSQResult(z=(B, G*C, T), codes=(B, G, T4),
+        latents=(B, G*C, T4)); differentiable (straight-through FSQ) through the native backward."""
+        _lib.require_cuda(z, "z")
+        cg = self.input_dim // self.groups
+        if z.ndim != 3 or z.shape[1] != cg or z.shape[0] % self.groups:
+            raise ValueError(f"expected (B*{self.groups}, {cg}, T), got {tuple(z.shape)}")
+        if z.shape[2] // math.prod(self.downsample_factor) < 1:
+            raise ValueError(f"T={z.shape[2]} is shorter than the downsampling factor")
+        if not getattr(self, "_want_train", False):
+            self._want_train = True
+            self._free_native()
+        zq, ids, lat = _QuantizerTrainFn.apply(self, z.float().contiguous(), *list(self.parameters()))
+        B = z.shape[0] // self.groups
+        return FSQResult(z=zq.view(B, self.input_dim, -1), codes=ids, latents=lat.view(B, self.input_dim, -1))

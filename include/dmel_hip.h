@@ -178,6 +178,19 @@ int dmel_quantizer_encode(const dmel_quantizer* q, const float* z, int32_t* ids,
 /* ids (B, G, T4) -> z (B, G*C, T4*prod(factors)) */
 int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids, float* z, int B, int64_t T4,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* Training path of the quantiser: DownsampleFiniteScalarQuantize.forward (dowmsample_fsq.py:86-122) with the straight-through FSQ of
+ * vector_quantize_pytorch, and its backward.  z (B*G, Cg, T) -> zq (B*G, Cg, T) (= (B, G*Cg, T); zero-padded from 2^nf * T4 back to T
+ * with left = diff / 2), ids (B, G, T4) and latents (B*G, Cg, T4) (both nullable).  Same conventions as the WaveNet training entry
+ * points (enable_training before finalize; the workspace of forward_train is handed to backward unchanged; one flat gradient buffer
+ * addressed through grad_slot with the state-dict keys).  dz is always produced. */
+int dmel_quantizer_enable_training(dmel_quantizer* q, int on);
+size_t dmel_quantizer_train_workspace_bytes(const dmel_quantizer* q, int B, int64_t T);
+int64_t dmel_quantizer_grad_floats(const dmel_quantizer* q);
+int dmel_quantizer_grad_slot(const dmel_quantizer* q, const char* key, int64_t* offset, int64_t* numel);
+int dmel_quantizer_forward_train(const dmel_quantizer* q, const float* z, float* zq, int32_t* ids /*nullable*/,
+                                 float* latents /*nullable*/, int B, int64_t T, void* workspace, size_t workspace_bytes, void* stream);
+int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, const float* dzq, float* dz, float* grads, int B, int64_t T,
+                            void* workspace, size_t workspace_bytes, void* stream);
 
 /* z[b,c,t] = z[b,c,t] * (t < lengths[b]) + (w[c] * value + bias[c])      codec_lit_modules.py:520-526
  * (quality_projection = nn.Linear(1, C) applied to the constant 2.0).  w, bias: device (C). */

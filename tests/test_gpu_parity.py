@@ -852,3 +852,42 @@ def test_convnext_block_forward_backward(dev, dim, N, T):
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         assert rel_err(p.grad, sd64[k].grad) < 5e-5, (k, rel_err(p.grad, sd64[k].grad))
+
+
+@pytest.mark.parametrize("levels,prebound,G,T,B", [([7, 5, 5], True, 3, 93, 2), ([7, 5, 5], False, 2, 64, 3), ([8, 6], True, 2, 47, 2)])
+def test_quantizer_training_forward_backward(dev, levels, prebound, G, T, B):
+    """DownsampleFiniteScalarQuantize.forward (straight-through FSQ, pad back to T) and its hand-written backward against autograd
+    through the oracle in float64: output, ids, input gradient and the gradient of all 13 * 4 + 4 * G parameter tensors."""
+    from dmel_codec_amd.models.modules.dowmsample_fsq import DownsampleFiniteScalarQuantize
+    torch.manual_seed(T + G)
+    Cg = 70
+    q = DownsampleFiniteScalarQuantize(input_dim=Cg * G, n_codebooks=1, n_groups=G, levels=levels, downsample_factor=[2, 2],
+                                       is_dmel=True, fsq_prebound=prebound)
+    randomise(q, 91 + G, scale=1.5)
+    with torch.no_grad():
+        for m in q.modules():
+            if hasattr(m, "gamma"):
+                m.gamma.normal_(0, 0.5)
+    sd64 = {k: v.double().requires_grad_() for k, v in cpu_sd(q).items()}
+    z = torch.randn(B * G, Cg, T)
+    gz = torch.randn(B, Cg * G, T)
+    z64 = z.double().requires_grad_()
+    zq64, ids64, lat64 = ref_cpu.quantizer_forward(sd64, "", z64, G, levels, (2, 2), prebound)
+    (zq64 * gz.double()).sum().backward()
+    q = q.to(dev)
+    zd = z.to(dev).requires_grad_()
+    res = q(zd)
+    assert res.z.shape == zq64.shape and res.codes.shape == ids64.shape and res.latents.shape == lat64.shape
+    assert rel_err(res.latents, lat64) < 2e-5
+    # a latent within rounding noise of a quantisation boundary may legitimately round the other way: compare where ids agree
+    same = (res.codes.cpu() == ids64.cpu())
+    assert same.float().mean() > 0.98
+    if bool(same.all()):
+        assert rel_err(res.z, zq64) < 5e-5
+        (res.z * gz.to(dev)).sum().backward()
+        assert rel_err(zd.grad, z64.grad) < 1e-4
+        for k, p in q.named_parameters():
+            assert p.grad is not None, k
+            assert rel_err(p.grad, sd64[k].grad) < 2e-4, (k, rel_err(p.grad, sd64[k].grad))
+    else:
+        pytest.skip("a latent sits on a rounding boundary for this seed")
