@@ -16,7 +16,7 @@ from torch import nn
 
 from .. import _lib
 from ..utils.spectrogram import LogMelSpectrogram
-from ..utils.utils import sequence_mask
+from ..utils.utils import avg_with_mask, sequence_mask
 from .modules.bigvgan.bigvgan import BigVGAN
 from .modules.dowmsample_fsq import DownsampleFiniteScalarQuantize
 from .modules.wavenet import WaveNet
@@ -84,6 +84,47 @@ class VQGAN(nn.Module):
     @staticmethod
     def _lengths(v: torch.Tensor) -> torch.Tensor:
         return v.squeeze(0) if v.ndim == 2 else v      # collate emits (1, B): utils/utils.py:50-51
+
+    # ------------------------------------------------------------------------------ training (generator half)
+    def generator_forward(self, audios, audio_lengths, noise: Optional[torch.Tensor] = None):
+        """The generator half of training_step (codec_lit_modules.py:164-211), differentiable through the native training paths of
+        the encoder, the quantiser (straight-through FSQ) and the decoder: returns gen_mel, gt_mels (masked), mel_masks_float_conv.
+        `noise` (extension) injects the decoder's Gaussian input, which the reference draws internally (:206)."""
+        if self.decoder is None:
+            raise ValueError("Decoder is not loaded")
+        audios = audios.float()
+        audio_lengths = self._lengths(audio_lengths)
+        with torch.no_grad():                                                                  # :170-174
+            encode_mels = self.encode_mel_transform(audios)
+            gt_mels = (self.gt_mel_transform or self.encode_mel_transform)(audios)
+            quality = ((gt_mels.mean(-1) > -8).sum(-1) - 90) / 10
+            quality = quality.unsqueeze(-1)
+        mel_lengths = audio_lengths.to(gt_mels.device) // (self.gt_mel_transform or self.encode_mel_transform).hop_length
+        mel_masks = sequence_mask(mel_lengths, gt_mels.shape[2])                                # :176-179
+        mel_masks_float_conv = mel_masks[:, None, :].to(torch.float32)
+        gt_mels = gt_mels * mel_masks_float_conv
+        dmel_masks = self.expand_mask(mel_masks_float_conv)                                     # :182-190
+        batch_size, num_mels, time_size = encode_mels.shape
+        encode_dmels = encode_mels.contiguous().view(batch_size * self.dmel_groups, num_mels // self.dmel_groups, time_size)
+        encode_dmels = encode_dmels * dmel_masks
+        encoded_features = self.encoder(encode_dmels) * dmel_masks
+        vq_result = self.quantizer(encoded_features)                                            # :197
+        vq_recon_features = vq_result.z * mel_masks_float_conv                                  # :199-202
+        vq_recon_features = vq_recon_features + self.quality_projection(quality.to(torch.float32))[:, :, None]
+        if noise is None:
+            noise = torch.randn_like(vq_recon_features)
+        gen_mel = self.decoder(noise * mel_masks_float_conv, condition=vq_recon_features * mel_masks_float_conv) * mel_masks_float_conv
+        return gen_mel, gt_mels, mel_masks_float_conv
+
+    @staticmethod
+    def mel_loss(gen_mel, gt_mels, mel_masks_float_conv):
+        """codec_lit_modules.py:246-263: band-weighted masked L1."""
+        mel_distance = (gen_mel - gt_mels).abs()
+        low = avg_with_mask(mel_distance[:, :40, :], mel_masks_float_conv)
+        mid = avg_with_mask(mel_distance[:, 40:70, :], mel_masks_float_conv)
+        high = avg_with_mask(mel_distance[:, 70:, :], mel_masks_float_conv)
+        allb = avg_with_mask(mel_distance, mel_masks_float_conv)
+        return (low * 0.6 + mid * 0.3 + high * 0.1) * 0.5 + allb * 0.5
 
     # ------------------------------------------------------------------------------ encode side
     @torch.no_grad()

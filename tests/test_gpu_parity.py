@@ -891,3 +891,48 @@ def test_quantizer_training_forward_backward(dev, levels, prebound, G, T, B):
             assert rel_err(p.grad, sd64[k].grad) < 2e-4, (k, rel_err(p.grad, sd64[k].grad))
     else:
         pytest.skip("a latent sits on a rounding boundary for this seed")
+
+
+def test_generator_half_of_training_step(dev):
+    """VQGAN.generator_forward + mel_loss (codec_lit_modules.py:164-211, 246-263) on the native training paths -- STFT front end,
+    grouped encoder WaveNet, straight-through quantiser, quality projection, conditioned decoder WaveNet, masks, band-weighted L1 --
+    against the same chain through the oracle with autograd in float64: loss, gen_mel and the gradient of EVERY trainable parameter
+    of encoder, quantiser, decoder and quality_projection.  Ragged lengths; the decoder noise is injected."""
+    from dmel_codec_amd.configs import oracle_cfg
+    codec = make_codec(1234, n_mels=80, dmel_groups=8, encoder_layers=3, decoder_layers=2, vocoder=None)
+    with torch.no_grad():
+        for m in codec.quantizer.modules():
+            if hasattr(m, "gamma"):
+                m.gamma.normal_(0, 0.3)
+    cfg = oracle_cfg(codec)
+    sd, _ = split_sd(codec)
+    gen = torch.Generator().manual_seed(11)
+    L = 9000
+    audio = torch.randn(3, 1, L, generator=gen) * 0.2
+    lens = torch.tensor([L, 5000, 7777])
+    T = L // 256
+    noise = torch.randn(3, 560, T, generator=gen)
+    sd64 = {k: (v.double().requires_grad_() if v.is_floating_point() else v) for k, v in sd.items()}
+    loss64, gen64, gt64 = ref_cpu.vqgan_generator_loss(sd64, cfg, audio, lens, noise)
+    loss64.backward()
+
+    codec = codec.to(dev)
+    gen_mel, gt_mels, masks = codec.generator_forward(audio.to(dev), lens.to(dev), noise=noise.to(dev))
+    loss = codec.mel_loss(gen_mel, gt_mels, masks)
+    assert rel_err(gt_mels, gt64) < 1e-4
+    assert rel_err(gen_mel, gen64) < 1e-4
+    assert abs(loss.item() - loss64.item()) < 1e-4 * abs(loss64.item())
+    loss.backward()
+    n_checked = 0
+    for k, p in codec.named_parameters():
+        if "diffusion_projection" in k or k.startswith("vocoder."):
+            continue
+        ref = sd64[k].grad
+        assert p.grad is not None and ref is not None, k
+        scale = ref.abs().max().item()
+        if scale < 1e-12:
+            assert p.grad.abs().max().item() < 1e-9, k
+        else:
+            assert rel_err(p.grad, ref) < 2e-3, (k, rel_err(p.grad, ref))
+        n_checked += 1
+    assert n_checked >= 100
