@@ -84,6 +84,7 @@ PROTOTYPES = {
     "dmel_quantizer_encode": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_quantizer_decode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_quantizer_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_quantizer_refresh": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), vp]),
     "dmel_quantizer_train_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_quantizer_grad_floats": (C.c_int64, [vp]),
     "dmel_quantizer_grad_slot": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

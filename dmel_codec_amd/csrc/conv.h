@@ -44,11 +44,15 @@ struct RepackSeg {
   const float* w = nullptr;
   int64_t rs = 0, cs = 0, ts = 0;
   int rev = 0;
+  // phase-major packed rows (transposed convs): source row sr = ph * pC + c addresses w[c * rs + ph * ps + ...] when pC > 0
+  int64_t ps = 0;
+  int pC = 0;
 };
 struct RepackSrc {
   RepackSeg seg[2];
   const float* b0 = nullptr;
   const float* b1 = nullptr;
+  int bias_mod = 0;          // > 0: the bias of source row sr is b0[sr % bias_mod] (one bias per output channel, shared by the phases)
 };
 int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t stream);
 

@@ -1045,6 +1045,89 @@ extern "C" int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids
   return DMEL_OK;
 }
 
+// Re-pack every weight image and parameter buffer of a finalized quantiser from device tensors (after an optimiser step).
+extern "C" int dmel_quantizer_refresh(dmel_quantizer* q, int n, const char* const* keys, const float* const* device_tensors, void* stream) {
+  DMEL_CHECK_ARG(q && keys && device_tensors && n > 0, "quantizer_refresh: bad argument");
+  if (!q->ready) { set_error("quantizer_refresh: handle not finalized"); return DMEL_EMISSING; }
+  std::map<std::string, const float*> dev;
+  for (int i = 0; i < n; ++i) {
+    DMEL_CHECK_ARG(keys[i] && device_tensors[i], "quantizer_refresh: NULL entry %d", i);
+    dev[keys[i]] = device_tensors[i];
+  }
+  bool missing = false;
+  auto T = [&](const std::string& k) -> const float* {
+    auto it = dev.find(k);
+    if (it == dev.end()) { set_error("quantizer_refresh: tensor '%s' was not provided", k.c_str()); missing = true; return nullptr; }
+    return it->second;
+  };
+  hipStream_t st = (hipStream_t)stream;
+  const int C = q->Cg, G = q->G, D = q->D;
+  auto copy = [&](DevBuf& dst, const float* src, size_t count) -> int {
+    if (!src) return DMEL_EMISSING;
+    DMEL_HIP(hipMemcpyAsync(dst.p, src, count * sizeof(float), hipMemcpyDeviceToDevice, st));
+    return DMEL_OK;
+  };
+  auto seg = [](const float* w, int64_t rs, int64_t cs, int64_t ps = 0, int pC = 0) {
+    RepackSeg s;
+    s.w = w; s.rs = rs; s.cs = cs; s.ps = ps; s.pC = pC;
+    return s;
+  };
+  auto refresh_cx = [&](ConvNeXt& cx, PackedConv* pw1T, PackedConv* pw2T, const std::string& p) -> int {
+    const float *w1 = T(p + "pwconv1.weight"), *b1 = T(p + "pwconv1.bias"), *w2 = T(p + "pwconv2.weight"), *b2 = T(p + "pwconv2.bias");
+    const float *dw = T(p + "dwconv.weight"), *db = T(p + "dwconv.bias"), *lw = T(p + "norm.weight"), *lb = T(p + "norm.bias");
+    const float* ga = T(p + "gamma");
+    if (missing) return DMEL_EMISSING;
+    DMEL_TRY(copy(cx.dw_w, dw, (size_t)C * 7)); DMEL_TRY(copy(cx.dw_b, db, C)); DMEL_TRY(copy(cx.ln_w, lw, C));
+    DMEL_TRY(copy(cx.ln_b, lb, C)); DMEL_TRY(copy(cx.gamma, ga, C));
+    RepackSrc a; a.seg[0] = seg(w1, C, 1); a.b0 = b1;
+    DMEL_TRY(launch_repack(cx.pw1, a, st));
+    RepackSrc b; b.seg[0] = seg(w2, 4 * C, 1); b.b0 = b2;
+    DMEL_TRY(launch_repack(cx.pw2, b, st));
+    if (pw1T) {
+      RepackSrc c; c.seg[0] = seg(w1, 1, C);
+      DMEL_TRY(launch_repack(*pw1T, c, st));
+      RepackSrc d; d.seg[0] = seg(w2, 1, 4 * C);
+      DMEL_TRY(launch_repack(*pw2T, d, st));
+    }
+    return DMEL_OK;
+  };
+  for (int i = 0; i < q->nf; ++i) {
+    const std::string pd = "downsample." + std::to_string(i) + ".", pu = "upsample." + std::to_string(i) + ".";
+    const float *wd = T(pd + "0.weight"), *bd = T(pd + "0.bias"), *wu = T(pu + "0.weight"), *bu = T(pu + "0.bias");
+    if (missing) return DMEL_EMISSING;
+    {  // value(sg, row, ci) = wd[(row*C + ci)*2 + sg]
+      RepackSrc a; a.seg[0] = seg(wd, 2 * C, 2); a.seg[1] = seg(wd + 1, 2 * C, 2); a.b0 = bd;
+      DMEL_TRY(launch_repack(q->down[i], a, st));
+    }
+    {  // value(row = (ph, co), ci) = wu[(ci*C + co)*2 + ph]; bias[co]
+      RepackSrc a; a.seg[0] = seg(wu, 2, 2 * C, 1, C); a.b0 = bu; a.bias_mod = C;
+      DMEL_TRY(launch_repack(q->up[i], a, st));
+    }
+    DMEL_TRY(refresh_cx(q->down_cx[i], q->train_ready ? &q->down_pw1T[i] : nullptr, q->train_ready ? &q->down_pw2T[i] : nullptr, pd + "1."));
+    DMEL_TRY(refresh_cx(q->up_cx[i], q->train_ready ? &q->up_pw1T[i] : nullptr, q->train_ready ? &q->up_pw2T[i] : nullptr, pu + "1."));
+    if (q->train_ready) {
+      {  // value(row = (ph, ci), cc) = wd[(cc*C + ci)*2 + ph]
+        RepackSrc a; a.seg[0] = seg(wd, 2, 2 * C, 1, C);
+        DMEL_TRY(launch_repack(q->down_dx[i], a, st));
+      }
+      {  // value(sg, row, cc) = wu[(row*C + cc)*2 + sg]
+        RepackSrc a; a.seg[0] = seg(wu, 2 * C, 2); a.seg[1] = seg(wu + 1, 2 * C, 2);
+        DMEL_TRY(launch_repack(q->up_dx[i], a, st));
+      }
+    }
+  }
+  for (int g = 0; g < G; ++g) {
+    const std::string p = "residual_fsq.rvqs." + std::to_string(g) + ".";
+    const float *a = T(p + "project_in.weight"), *ab = T(p + "project_in.bias"), *o = T(p + "project_out.weight"), *ob = T(p + "project_out.bias");
+    if (missing) return DMEL_EMISSING;
+    DMEL_HIP(hipMemcpyAsync(q->w_in.as<float>() + (size_t)g * D * C, a, (size_t)D * C * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DMEL_HIP(hipMemcpyAsync(q->b_in.as<float>() + (size_t)g * D, ab, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DMEL_HIP(hipMemcpyAsync(q->w_out.as<float>() + (size_t)g * C * D, o, (size_t)C * D * sizeof(float), hipMemcpyDeviceToDevice, st));
+    DMEL_HIP(hipMemcpyAsync(q->b_out.as<float>() + (size_t)g * C, ob, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
+  }
+  return DMEL_OK;
+}
+
 // ---- quantiser training path: DownsampleFiniteScalarQuantize.forward (dowmsample_fsq.py:86-122) and its backward ----------
 namespace {
 struct QStage { float* in; float* conv; CxPlan cx; int64_t Tin, Tout; };      // input of the (transposed) conv, its output = ConvNeXt input

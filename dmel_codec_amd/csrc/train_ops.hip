@@ -233,6 +233,7 @@ struct RepackArgs {
   RepackSeg seg[2];
   const float* b0;
   const float* b1;
+  int bias_mod;
   float* w;
   uint16_t* w16;
   uint16_t* w48;
@@ -267,7 +268,8 @@ __global__ void repack_kernel(RepackArgs a) {
     if (sr >= 0 && ci < a.Cin[sg]) {
       const RepackSeg& s = a.seg[sg];
       const int t = s.rev ? a.taps[sg] - 1 - tp : tp;
-      v = s.w[sr * s.rs + ci * s.cs + t * s.ts];
+      const int64_t ro = s.pC > 0 ? (int64_t)(sr % s.pC) * s.rs + (int64_t)(sr / s.pC) * s.ps : (int64_t)sr * s.rs;
+      v = s.w[ro + ci * s.cs + t * s.ts];
     }
     const int tile = m >> 5, r = m & 31;
     {  // fp32 image: [tile][step][half][lane][4], lane = 32*(k&1) + r
@@ -291,8 +293,9 @@ __global__ void repack_kernel(RepackArgs a) {
     if (step == 0 && k == 0) {
       float b = 0.f;
       if (sr >= 0) {
-        if (a.b0) b = a.b0[sr];
-        if (a.b1) b += a.b1[sr];
+        const int bi = a.bias_mod > 0 ? sr % a.bias_mod : sr;
+        if (a.b0) b = a.b0[bi];
+        if (a.b1) b += a.b1[bi];
       }
       a.bias[m] = b;
     }
@@ -305,7 +308,7 @@ int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t s) {
   DMEL_CHECK_ARG(d.nseg >= 1 && d.nseg <= 2 && src.seg[0].w && (d.nseg == 1 || src.seg[1].w), "repack: missing source tensor");
   RepackArgs a{};
   a.seg[0] = src.seg[0]; a.seg[1] = src.seg[1];
-  a.b0 = src.b0; a.b1 = src.b1;
+  a.b0 = src.b0; a.b1 = src.b1; a.bias_mod = src.bias_mod;
   a.w = pc.w.as<float>(); a.w16 = pc.w16.as<uint16_t>(); a.w48 = pc.w48.as<uint16_t>(); a.bias = pc.bias.as<float>();
   a.mode = d.mode; a.C = d.C; a.RP = pc.RP; a.phases = d.phases; a.nseg = d.nseg; a.Mpad = pc.Mpad; a.steps = pc.steps;
   for (int i = 0; i < d.nseg; ++i) {

@@ -18,6 +18,7 @@ class NativeModule(nn.Module):
     _set_symbol = ""
     _finalize_symbol = ""
     _precision_symbol = ""   # modules whose convolutions have the opt-in bf16 mode name their dmel_*_set_precision here
+    _refresh_symbol = ""     # modules that can re-pack their weight images from device tensors name their dmel_*_refresh here
 
     def __init__(self):
         super().__init__()
@@ -36,8 +37,27 @@ class NativeModule(nn.Module):
     def _create_native(self) -> int:
         raise NotImplementedError
 
+    def _native_state_refs(self):
+        """(key, live tensor) of the tensors the native handle is built from -- no copies (device-side refresh)."""
+        keys = set(self._native_state().keys())
+        return [(k, p.data) for k, p in self.named_parameters() if k in keys]
+
     def native(self) -> int:
         ver = self._versions()
+        if self._refresh_symbol and self._handle is not None and ver != self._handle_versions:
+            # only the VALUES of CUDA parameters changed (an optimiser step): re-pack the existing handle's weight images on the
+            # device instead of rebuilding the handle through the host
+            old = self._handle_versions
+            same = old is not None and len(old) == len(ver) and all(a[0] == b[0] for a, b in zip(old, ver))
+            items = self._native_state_refs()
+            if same and items and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() for _, v in items):
+                keys = (C.c_char_p * len(items))(*[k.encode() for k, _ in items])
+                ptrs = (C.c_void_p * len(items))(*[v.data_ptr() for _, v in items])
+                with torch.cuda.device(items[0][1].device):
+                    _lib.check(getattr(_lib.lib(), self._refresh_symbol)(self._handle, len(items), keys, ptrs, _lib.stream_ptr()),
+                               f"{type(self).__name__}.refresh")
+                self._handle_versions = ver
+                return self._handle
         if self._handle is None or ver != self._handle_versions:
             self._free_native()
             L = _lib.lib()

@@ -111,6 +111,7 @@ class WaveNet(NativeModule):
     _set_symbol = "dmel_wavenet_set_tensor"
     _finalize_symbol = "dmel_wavenet_finalize"
     _precision_symbol = "dmel_wavenet_set_precision"
+    _refresh_symbol = "dmel_wavenet_refresh"
 
     def __init__(self, input_channels: Optional[int] = None, output_channels: Optional[int] = None,
                  residual_channels: int = 512, residual_layers: int = 20, dilation_cycle: Optional[int] = 4,
@@ -158,28 +159,6 @@ class WaveNet(NativeModule):
         if getattr(self, "_want_train", False):
             _lib.check(_lib.lib().dmel_wavenet_enable_training(h, 1), "wavenet_enable_training")
         return h.value
-
-    def native(self) -> int:
-        """As NativeModule.native(), but when only the VALUES of CUDA parameters changed (an optimiser step) the existing
-        handle's weight images are re-packed on the device (dmel_wavenet_refresh) instead of being rebuilt through the host."""
-        ver = self._versions()
-        if self._handle is not None and ver != self._handle_versions:
-            old = self._handle_versions
-            same_tensors = old is not None and len(old) == len(ver) and all(a[0] == b[0] for a, b in zip(old, ver))
-            items = [(k, v) for k, v in self._native_state_refs()]
-            if same_tensors and items and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() for _, v in items):
-                keys = (C.c_char_p * len(items))(*[k.encode() for k, _ in items])
-                ptrs = (C.c_void_p * len(items))(*[v.data_ptr() for _, v in items])
-                with torch.cuda.device(items[0][1].device):
-                    _lib.check(_lib.lib().dmel_wavenet_refresh(self._handle, len(items), keys, ptrs, _lib.stream_ptr()),
-                               "wavenet_refresh")
-                self._handle_versions = ver
-                return self._handle
-        return super().native()
-
-    def _native_state_refs(self):
-        """(key, live tensor) of the tensors the native handle is built from -- no copies."""
-        return [(k, p.data) for k, p in self.named_parameters() if "diffusion_projection" not in k]
 
     def _trained_parameters(self):
         """(state-dict key, parameter) of everything the native backward produces a gradient for, in a fixed order

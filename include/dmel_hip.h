@@ -184,6 +184,8 @@ int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids, float* z,
  * points (enable_training before finalize; the workspace of forward_train is handed to backward unchanged; one flat gradient buffer
  * addressed through grad_slot with the state-dict keys).  dz is always produced. */
 int dmel_quantizer_enable_training(dmel_quantizer* q, int on);
+/* as dmel_wavenet_refresh: re-pack every weight image / parameter buffer from device tensors named by their state-dict keys */
+int dmel_quantizer_refresh(dmel_quantizer* q, int n, const char* const* keys, const float* const* device_tensors, void* stream);
 size_t dmel_quantizer_train_workspace_bytes(const dmel_quantizer* q, int B, int64_t T);
 int64_t dmel_quantizer_grad_floats(const dmel_quantizer* q);
 int dmel_quantizer_grad_slot(const dmel_quantizer* q, const char* key, int64_t* offset, int64_t* numel);

@@ -891,6 +891,25 @@ def test_quantizer_training_forward_backward(dev, levels, prebound, G, T, B):
             assert rel_err(p.grad, sd64[k].grad) < 2e-4, (k, rel_err(p.grad, sd64[k].grad))
     else:
         pytest.skip("a latent sits on a rounding boundary for this seed")
+    # optimiser-style in-place update: the handle is re-packed on the device, bit-identically to a rebuild through the host
+    h_before = q._handle
+    with torch.no_grad():
+        for p in q.parameters():
+            p.mul_(1.003)
+        r1 = q(zd.detach())
+        ids1 = q.encode(zd.detach())
+        dec1 = q.decode(ids1)
+        assert q._handle == h_before
+        q._free_native()
+        r2 = q(zd.detach())
+        assert torch.equal(r1.z, r2.z) and torch.equal(r1.codes, r2.codes) and torch.equal(r1.latents, r2.latents)
+        assert torch.equal(q.encode(zd.detach()), ids1) and torch.equal(q.decode(ids1), dec1)
+    g1 = torch.autograd.grad(q(zd.detach()).z.sum(), q.downsample[0][0].weight)[0]
+    with torch.no_grad():
+        for p in q.parameters():
+            p.mul_(1.0)
+    g2 = torch.autograd.grad(q(zd.detach()).z.sum(), q.downsample[0][0].weight)[0]
+    assert rel_err(g2, g1) < 1e-6
 
 
 def test_generator_half_of_training_step(dev):
