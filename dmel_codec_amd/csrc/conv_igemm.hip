@@ -77,8 +77,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
     const int ycs = (int)a.y_cs, rcs = (int)a.res_cs, tout = (int)a.Tout;
     // The common case (plain conv, optionally + residual: 5 of 6 vocoder convs, every WaveNet projection) gets a loop
     // with no per-element flag tests: the general loop below spends more time in uniform branches than in stores.
-    const bool lean = a.act == ACT_NONE && !a.row_scale && a.out_div == 1.f && a.phases == 1 && a.out_tstride == 1 &&
-                      !a.accumulate && a.phase_base == 0;
+    const bool lean = a.act == ACT_NONE && !a.row_scale && a.phases == 1 && a.out_tstride == 1 && a.phase_base == 0;
     if (lean) {
       const int tlim = min(tcols, tout);
       bool colok[NT], live[NT];
@@ -97,6 +96,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
         for (int g = 0; g < 4; ++g) {           // four rows at a time: all their loads are issued before the first use
           float bias[4], rv[4][NT];
           int co[4];
+          float ov[4][NT];          // previous output, for the running sum of the AMP branches (accumulate)
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             co[k] = mtile + k + 8 * g + 4 * h;
@@ -105,6 +105,10 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
             if (rb) {
 #pragma unroll
               for (int ni = 0; ni < NT; ++ni) rv[k][ni] = rb[cc * rcs + cq[ni]];
+            }
+            if (a.accumulate) {
+#pragma unroll
+              for (int ni = 0; ni < NT; ++ni) ov[k][ni] = yb[cc * ycs + cq[ni]];
             }
           }
 #pragma unroll
@@ -115,6 +119,8 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
             for (int ni = 0; ni < NT; ++ni) {
               float v = acc[mi][ni][4 * g + k] + bias[k];
               if (rb) v += rv[k][ni];
+              if (a.accumulate) v += ov[k][ni];
+              if (a.out_div != 1.f) v = v / a.out_div;
               if (colok[ni]) yrow[ni * 32] = live[ni] ? v : 0.f;
             }
           }
