@@ -139,3 +139,45 @@ def test_schedule_fixture(golden):
                          for s in g.ins["steps"]])
     assert torch.allclose(vals, g.outs["lr"], atol=1e-7)
     assert lr_lambda(10, num_warmup_steps=0.1, num_training_steps=1000) == 0.1      # fractional warm-up
+
+
+def _oracle_grads(y, dy, leaves):
+    (y * dy).sum().backward()
+    return {k: v.grad for k, v in leaves.items()}
+
+
+def test_training_gradients_match_reference(golden):
+    """The GPU training tests use autograd through the oracle (in float64) as their truth; these fixtures hold what autograd through
+    the REFERENCE's own modules produced (oracle/gen_golden_grads.py), so the oracle's backward is pinned to the reference too."""
+    g = golden("train_grads_wavenet")
+    sd = {k: v.clone().requires_grad_() for k, v in g.sd.items()}
+    x, c = g.ins["x"].clone().requires_grad_(), g.ins["cond"].clone().requires_grad_()
+    y = ref_cpu.wavenet_forward(sd, "", x, g.meta["n_layers"], g.meta["dilation_cycle"], c)
+    assert rel_err(y, g.outs["y"]) < 5e-6
+    (y * g.ins["dy"]).sum().backward()
+    assert rel_err(x.grad, g.outs["d_x"]) < 2e-5 and rel_err(c.grad, g.outs["d_cond"]) < 2e-5
+    n = 0
+    for k, ref in g.outs.items():
+        if k.startswith("g/"):
+            assert rel_err(sd[k[2:]].grad, ref) < 5e-5, k
+            n += 1
+    assert n == len([k for k in g.sd if "diffusion_projection" not in k])
+    assert all(sd[k].grad is None for k in g.sd if "diffusion_projection" in k)      # dead parameters, in the reference too
+
+    g = golden("train_grads_convnext")
+    sd = {k: v.clone().requires_grad_() for k, v in g.sd.items()}
+    x = g.ins["x"].clone().requires_grad_()
+    y = ref_cpu.convnext_block(sd, "", x)
+    (y * g.ins["dy"]).sum().backward()
+    assert rel_err(y, g.outs["y"]) < 5e-6 and rel_err(x.grad, g.outs["d_x"]) < 2e-5
+    for k, ref in g.outs.items():
+        if k.startswith("g/"):
+            assert rel_err(sd[k[2:]].grad, ref) < 5e-5, k
+
+    g = golden("train_grads_activation1d")
+    a, b = g.sd["act.alpha"].clone().requires_grad_(), g.sd["act.beta"].clone().requires_grad_()
+    x = g.ins["x"].clone().requires_grad_()
+    y = ref_cpu.activation1d(x, a, b, g.sd["upsample.filter"], g.sd["downsample.lowpass.filter"], logscale=True)
+    (y * g.ins["dy"]).sum().backward()
+    assert rel_err(y, g.outs["y"]) < 5e-6 and rel_err(x.grad, g.outs["d_x"]) < 2e-5
+    assert rel_err(a.grad, g.outs["g/act.alpha"]) < 5e-5 and rel_err(b.grad, g.outs["g/act.beta"]) < 5e-5
