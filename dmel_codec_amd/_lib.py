@@ -50,6 +50,13 @@ PROTOTYPES = {
     "dmel_stft_logmel_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_aa_snake_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_aa_snake_backward_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    "dmel_discriminator_create": (C.c_int, [C.POINTER(vp)]),
+    "dmel_discriminator_destroy": (None, [vp]),
+    "dmel_discriminator_set_tensor": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]),
+    "dmel_discriminator_finalize": (C.c_int, [vp]),
+    "dmel_discriminator_out_frames": (C.c_int64, [vp, C.c_int64]),
+    "dmel_discriminator_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int64]),
+    "dmel_discriminator_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_convnext_create": (C.c_int, [C.POINTER(vp), C.c_int]),
     "dmel_convnext_destroy": (None, [vp]),
     "dmel_convnext_set_tensor": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]),

@@ -899,7 +899,10 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     const SegDesc& sd = d.seg[s];
     SegArgs& o = ka.seg[s];
     DMEL_CHECK_ARG(r.seg[s].x != nullptr, "conv: input pointer of segment %d is NULL", s);
-    DMEL_CHECK_ARG(sd.taps == 1 || sd.tstride == 1, "conv: taps>1 with strided input unsupported");
+    // taps on a strided view (polyphase branches of a stride-2 convolution: the discriminator) are staged correctly by the bf16
+    // matrix-core kernels only; the native fp32-MFMA kernels were never built for it
+    DMEL_CHECK_ARG(sd.taps == 1 || sd.tstride == 1 || (r.precision != DMEL_PRECISION_FP32_MFMA && !getenv("DMEL_CONV_FP32_MFMA")),
+                   "conv: taps>1 with strided input is unsupported by the native fp32-MFMA kernel");
     o.x = r.seg[s].x; o.bstride = r.seg[s].bstride; o.cstride = r.seg[s].cstride; o.Tin = r.seg[s].Tin;
     o.in_len = r.seg[s].in_len; o.in_scale = r.seg[s].in_scale;
     o.Cin = sd.Cin; o.nchunk = (sd.Cin + kCK - 1) / kCK; o.taps = sd.taps; o.dil = sd.dil;

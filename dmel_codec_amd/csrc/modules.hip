@@ -54,6 +54,21 @@ struct TensorStore {
       out = w->v;
       return true;
     }
+    if (find(prefix + "parametrizations.weight.original1")) {      // torch.nn.utils.parametrizations.weight_norm (dim 0)
+      const HostTensor* v1 = need(prefix + "parametrizations.weight.original1", shape);
+      const HostTensor* g1 = find(prefix + "parametrizations.weight.original0");
+      const int64_t n1 = *shape.begin();
+      if (!v1 || !g1 || g1->numel() != n1) { set_error("missing or mis-shaped '%sparametrizations.weight.original0'", prefix.c_str()); return false; }
+      const int64_t inner1 = v1->numel() / n1;
+      out.resize(v1->v.size());
+      for (int64_t i = 0; i < n1; ++i) {
+        double ss = 0;
+        for (int64_t j = 0; j < inner1; ++j) ss += (double)v1->v[i * inner1 + j] * v1->v[i * inner1 + j];
+        const float scale = g1->v[i] / (float)std::sqrt(ss);
+        for (int64_t j = 0; j < inner1; ++j) out[i * inner1 + j] = v1->v[i * inner1 + j] * scale;
+      }
+      return true;
+    }
     const HostTensor* v = need(prefix + "weight_v", shape);
     if (!v) { set_error("missing state-dict tensor '%sweight' (or weight_g/weight_v)", prefix.c_str()); return false; }
     const HostTensor* g = find(prefix + "weight_g");
@@ -1302,6 +1317,189 @@ extern "C" int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, 
     }
     if (i > 0) std::swap(g, other);
   }
+  return DMEL_OK;
+}
+
+// =====================================================================================================
+// Discriminator                                     models/modules/discriminator.py:6-35
+// =====================================================================================================
+// Six weight-normed Conv2d over the mel image (B, 1, H = n_mels, W = frames), kernels (3, kw), stride (1, sw), SiLU in between.
+// A (3, kw) Conv2d is three 1-D convolutions over W, one per kernel row dh, summed: y[:, h] += conv1d_dh(x[:, h + dh - 1]).
+// Activations are kept as (B, H + 2, C, W): one ITEM per image row with a zero pad row above and below every image, so that row
+// h + dh - 1 of the input is simply the neighbouring item (a pointer offset) and the implicit-GEMM conv kernel runs unchanged with
+// batch = B * (H + 2) items; the output rows of the pad items are forced to zero by the kernel's per-item length mask.  A stride-2
+// convolution over W is the sum of its two polyphase branches (even taps on x[2w'], odd taps on x[2w' + 1]): two K segments.
+namespace {
+struct DLayer {
+  int Cin, Cout, kw, sw, pw;
+  PackedConv fwd[3];                      // per kernel row dh
+  std::vector<float> w;                   // folded weight (Cout, Cin, 3, kw), kept for the training images
+};
+constexpr int kDiscLayers = 6;
+const int kDiscCfg[kDiscLayers][5] = {{1, 64, 9, 1, 4}, {64, 128, 9, 2, 4}, {128, 256, 9, 2, 4}, {256, 512, 9, 2, 4}, {512, 1024, 3, 1, 1},
+                                       {1024, 1, 3, 1, 1}};
+int64_t disc_out_w(const DLayer& l, int64_t W) { return (W + 2 * l.pw - l.kw) / l.sw + 1; }
+}  // namespace
+
+struct dmel_discriminator {
+  TensorStore ts;
+  bool ready = false;
+  DLayer layer[kDiscLayers];
+};
+
+extern "C" int dmel_discriminator_create(dmel_discriminator** out) {
+  DMEL_CHECK_ARG(out, "NULL out");
+  auto* d = new dmel_discriminator();
+  for (int i = 0; i < kDiscLayers; ++i) {
+    d->layer[i].Cin = kDiscCfg[i][0]; d->layer[i].Cout = kDiscCfg[i][1]; d->layer[i].kw = kDiscCfg[i][2]; d->layer[i].sw = kDiscCfg[i][3];
+    d->layer[i].pw = kDiscCfg[i][4];
+  }
+  *out = d;
+  return DMEL_OK;
+}
+extern "C" void dmel_discriminator_destroy(dmel_discriminator* d) { delete d; }
+extern "C" int dmel_discriminator_set_tensor(dmel_discriminator* d, const char* key, const float* data, const int64_t* shape, int ndim) {
+  DMEL_CHECK_ARG(d, "NULL handle");
+  d->ready = false;
+  return d->ts.set(key, data, shape, ndim);
+}
+
+static int disc_pack_forward(DLayer& l, const std::vector<float>& bias) {
+  const int Cin = l.Cin, kw = l.kw;
+  const std::vector<float>& w = l.w;
+  for (int dh = 0; dh < 3; ++dh) {
+    PackDesc d;
+    d.mode = EPI_LINEAR; d.C = l.Cout;
+    auto W = [&, dh](int row, int ci, int dw) { return w[(((size_t)row * Cin + ci) * 3 + dh) * kw + dw]; };
+    auto B = [&, dh](int row) { return dh == 1 ? bias[row] : 0.f; };     // the bias rides the centre row's launch
+    if (l.sw == 1) {
+      d.nseg = 1;
+      d.seg[0].Cin = Cin; d.seg[0].taps = kw; d.seg[0].dil = 1; d.seg[0].pad_left = l.pw;
+      DMEL_TRY(pack_conv(l.fwd[dh], d, [&](int, int row, int ci, int tap) { return W(row, ci, tap); }, B));
+    } else {
+      d.nseg = 2;                                                       // even taps on x[2w' + ...], odd taps on x[2w' + 1 + ...]
+      for (int sg = 0; sg < 2; ++sg) {
+        d.seg[sg].Cin = Cin; d.seg[sg].taps = (kw + 1 - sg) / 2; d.seg[sg].dil = 1; d.seg[sg].tstride = 2; d.seg[sg].toff = sg;
+        d.seg[sg].pad_left = l.pw;
+      }
+      DMEL_TRY(pack_conv(l.fwd[dh], d, [&](int sg, int row, int ci, int tap) { return W(row, ci, 2 * tap + sg); }, B));
+    }
+  }
+  return DMEL_OK;
+}
+
+extern "C" int dmel_discriminator_finalize(dmel_discriminator* d) {
+  DMEL_CHECK_ARG(d, "NULL handle");
+  for (int i = 0; i < kDiscLayers; ++i) {
+    DLayer& l = d->layer[i];
+    const std::string p = "blocks." + std::to_string(2 * i) + ".";
+    if (!d->ts.conv_weight(p, {l.Cout, l.Cin, 3, l.kw}, l.w)) return DMEL_EMISSING;
+    const HostTensor* b = d->ts.need(p + "bias", {l.Cout});
+    if (!b) return DMEL_EMISSING;
+    DMEL_TRY(disc_pack_forward(l, b->v));
+  }
+  d->ts.t.clear();
+  d->ready = true;
+  return DMEL_OK;
+}
+
+namespace {
+struct DPlan {
+  float* act[kDiscLayers + 1];        // act[0]: padded input image; act[i+1]: output of layer i (after SiLU for i < 5)
+  float* pre[kDiscLayers];            // pre-activation of layer i (training keeps it; inference aliases act[i+1])
+  int64_t* len[kDiscLayers];          // per-item valid output length of layer i (0 on the pad rows)
+  int64_t W[kDiscLayers + 1];
+  int64_t items;
+  size_t bytes;
+};
+// every activation buffer has one guard item in front and behind (rows -1 and B*(H+2) are read by the dh = 0 / 2 launches)
+DPlan disc_plan(const dmel_discriminator* d, int B, int H, int64_t W, bool train, void* ws) {
+  DPlan p{};
+  Arena a(ws, (size_t)-1);
+  p.items = (int64_t)B * (H + 2);
+  p.W[0] = W;
+  for (int i = 0; i < kDiscLayers; ++i) p.W[i + 1] = disc_out_w(d->layer[i], p.W[i]);
+  auto buf = [&](int C, int64_t Wl) { return a.take<float>((size_t)(p.items + 2) * C * Wl) + (size_t)C * Wl; };
+  p.act[0] = buf(1, W);
+  for (int i = 0; i < kDiscLayers; ++i) {
+    p.act[i + 1] = buf(d->layer[i].Cout, p.W[i + 1]);
+    p.pre[i] = (train && i < kDiscLayers - 1) ? buf(d->layer[i].Cout, p.W[i + 1]) : p.act[i + 1];
+    p.len[i] = a.take<int64_t>((size_t)p.items);
+  }
+  p.bytes = align_up(a.off, 256);
+  return p;
+}
+__global__ void disc_len_kernel(int64_t* len, int64_t items, int Hp, int64_t W) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < items) {
+    const int h = (int)(i % Hp);
+    len[i] = (h == 0 || h == Hp - 1) ? 0 : W;
+  }
+}
+// layer i forward into `out` (pre-activation): three launches, centre row first
+int disc_layer_forward(const dmel_discriminator* d, const DPlan& p, int i, const float* in, float* out, hipStream_t st) {
+  const DLayer& l = d->layer[i];
+  const int64_t Win = p.W[i], Wout = p.W[i + 1], istr = (int64_t)l.Cin * Win;
+  const int order[3] = {1, 0, 2};
+  for (int k = 0; k < 3; ++k) {
+    const int dh = order[k];
+    ConvRun r;
+    const int nseg = l.sw == 1 ? 1 : 2;
+    for (int sg = 0; sg < nseg; ++sg) {
+      r.seg[sg].x = in + (int64_t)(dh - 1) * istr; r.seg[sg].bstride = istr; r.seg[sg].cstride = Win; r.seg[sg].Tin = Win;
+    }
+    r.B = (int)p.items; r.Tcols = Wout; r.y = out; r.y_bs = (int64_t)l.Cout * Wout; r.y_cs = Wout; r.Tout = Wout;
+    r.out_len = p.len[i]; r.len_div = 1;
+    r.accumulate = k > 0;
+    DMEL_TRY(launch_conv(l.fwd[dh], r, st));
+  }
+  return DMEL_OK;
+}
+int disc_forward_common(const dmel_discriminator* d, const DPlan& p, const float* x, int B, int H, int64_t W, hipStream_t st) {
+  const int Hp = H + 2;
+  // zero everything once: pad rows, guard items (act[0] only needs its pads, the rest is overwritten, but one memset is simpler)
+  DMEL_HIP(hipMemsetAsync(p.act[0] - W, 0, (size_t)(p.items + 2) * W * sizeof(float), st));
+  DMEL_HIP(hipMemcpy2DAsync(p.act[0] + W, (size_t)Hp * W * sizeof(float), x, (size_t)H * W * sizeof(float), (size_t)H * W * sizeof(float), B,
+                            hipMemcpyDeviceToDevice, st));
+  for (int i = 0; i < kDiscLayers; ++i) {
+    const DLayer& l = d->layer[i];
+    const size_t n = (size_t)(p.items + 2) * l.Cout * p.W[i + 1];
+    DMEL_HIP(hipMemsetAsync(p.pre[i] - (size_t)l.Cout * p.W[i + 1], 0, n * sizeof(float), st));      // guards of the pre-activation buffer
+    hipLaunchKernelGGL(disc_len_kernel, dim3((unsigned)((p.items + 255) / 256)), dim3(256), 0, st, p.len[i], p.items, Hp, p.W[i + 1]);
+    DMEL_HIP(hipGetLastError());
+    DMEL_TRY(disc_layer_forward(d, p, i, p.act[i], p.pre[i], st));
+    if (i < kDiscLayers - 1) {
+      if (p.pre[i] != p.act[i + 1])
+        DMEL_HIP(hipMemsetAsync(p.act[i + 1] - (size_t)l.Cout * p.W[i + 1], 0, n * sizeof(float), st));
+      DMEL_TRY(launch_silu_fwd(p.pre[i], p.act[i + 1], (int64_t)p.items * l.Cout * p.W[i + 1], st));   // silu(0) = 0: pads stay zero
+    }
+  }
+  return DMEL_OK;
+}
+}  // namespace
+
+extern "C" int64_t dmel_discriminator_out_frames(const dmel_discriminator* d, int64_t W) {
+  if (!d || W <= 0) return 0;
+  for (int i = 0; i < kDiscLayers; ++i) W = disc_out_w(d->layer[i], W);
+  return W;
+}
+extern "C" size_t dmel_discriminator_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W) {
+  if (!d || B <= 0 || H <= 0 || W <= 0) return 0;
+  return disc_plan(d, B, H, W, false, nullptr).bytes;
+}
+// x (B, H, W) -> logits (B, H, W_out)           discriminator.py:34-35
+extern "C" int dmel_discriminator_forward(const dmel_discriminator* d, const float* x, float* y, int B, int H, int64_t W, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(d && x && y && workspace, "discriminator_forward: NULL argument");
+  if (!d->ready) { set_error("discriminator_forward: handle not finalized"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0 && (int64_t)B * (H + 2) < 2000000000, "discriminator_forward: bad shape");
+  const DPlan p = disc_plan(d, B, H, W, false, workspace);
+  DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "discriminator_forward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  DMEL_TRY(disc_forward_common(d, p, x, B, H, W, st));
+  const int64_t Wo = p.W[kDiscLayers];
+  DMEL_HIP(hipMemcpy2DAsync(y, (size_t)H * Wo * sizeof(float), p.act[kDiscLayers] + Wo, (size_t)(H + 2) * Wo * sizeof(float),
+                            (size_t)H * Wo * sizeof(float), B, hipMemcpyDeviceToDevice, st));
   return DMEL_OK;
 }
 

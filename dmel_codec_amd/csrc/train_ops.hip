@@ -53,7 +53,7 @@ __global__ void resskip_bwd_kernel(const float* __restrict__ gx, const float* __
   }
 }
 
-__global__ void silu_fwd_kernel(const float* __restrict__ u, float* __restrict__ y, int64_t total) {
+__global__ void silu_fwd_kernel(const float* u, float* y, int64_t total) {   // y may alias u
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const float v = u[i];
     y[i] = v * sigmoidf_(v);

@@ -231,6 +231,21 @@ int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, float* audio, 
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Discriminator (models/modules/discriminator.py:6-35): six weight-normed Conv2d (3 x 9 | 3 x 3, stride (1, 1|2)) + SiLU over the mel
+ * image.  set_tensor keys as in the reference's state dict: blocks.{0,2,..,10}.bias, blocks.{i}.parametrizations.weight.original0|1
+ * (weight norm is folded at finalize).  x (B, H = n_mels, W = frames) -> logits (B, H, dmel_discriminator_out_frames(W)).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dmel_discriminator dmel_discriminator;
+int dmel_discriminator_create(dmel_discriminator** d);
+void dmel_discriminator_destroy(dmel_discriminator* d);
+int dmel_discriminator_set_tensor(dmel_discriminator* d, const char* key, const float* data_host, const int64_t* shape, int ndim);
+int dmel_discriminator_finalize(dmel_discriminator* d);
+int64_t dmel_discriminator_out_frames(const dmel_discriminator* d, int64_t W);
+size_t dmel_discriminator_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W);
+int dmel_discriminator_forward(const dmel_discriminator* d, const float* x, float* y, int B, int H, int64_t W, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Single-op entry point for the implicit-GEMM conv kernel (tests, module mirrors).
  * y = conv1d(x, w, bias, dilation, padding = dilation*(k-1)/2)   w_host: (Cout, Cin, k) as nn.Conv1d stores it.
  * ---------------------------------------------------------------------------------------------- */

@@ -72,5 +72,32 @@ def main() -> None:
          m.state_dict(), {"x": x, "dy": dy}, outs)
 
 
+def disc_fixture() -> None:
+    """Discriminator: forward logits and autograd gradients of the reference class on seeded weights (the fixture carries the seed, the
+    input, the logits, d input, the gradients of the small tensors and seeded random projections of the large ones)."""
+    from dmel_codec.models.modules.discriminator import Discriminator
+    from oracle import ref_cpu
+    seed = 4242
+    m = Discriminator()
+    m.load_state_dict(ref_cpu.seeded_discriminator_sd(seed))
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(2, 80, 37, generator=g, requires_grad=True)
+    y = m(x)
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward()
+    outs = {"y": y.detach(), "d_x": x.grad.detach()}
+    for k, p in m.named_parameters():
+        if p.numel() <= 4096:
+            outs["g/" + k] = p.grad.detach()
+        else:
+            r = torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel()))
+            outs["proj/" + k] = (p.grad.detach() * r).sum().reshape(1)
+    save("train_grads_discriminator", {"pinned": True, "ref": "models/modules/discriminator.py:6-35 (+ autograd)", "seed": seed}, {},
+         {"x": x, "dy": dy}, outs)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "disc":
+        disc_fixture()
+        sys.exit(0)
     main()

@@ -955,3 +955,24 @@ def test_generator_half_of_training_step(dev):
             assert rel_err(p.grad, ref) < 2e-3, (k, rel_err(p.grad, ref))
         n_checked += 1
     assert n_checked >= 100
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 80, 37), (3, 100, 93), (1, 80, 12)])
+def test_discriminator_forward(dev, B, H, W):
+    """Native Discriminator forward (every (3, kw) Conv2d as three implicit-GEMM launches over zero-padded image rows; stride-2 layers as
+    two polyphase K segments) against the oracle, whose restatement is pinned to the reference class by a CPU fixture."""
+    from dmel_codec_amd.models.modules.discriminator import Discriminator
+    sd = ref_cpu.seeded_discriminator_sd(4242 + W)
+    d = Discriminator()
+    d.load_state_dict(sd)
+    torch.manual_seed(W)
+    x = torch.randn(B, H, W)
+    ref = ref_cpu.discriminator_forward(sd, "", x)
+    ref64 = ref_cpu.discriminator_forward({k: v.double() for k, v in sd.items()}, "", x.double())
+    d = d.to(dev)
+    with torch.no_grad():
+        y = d(x.to(dev))
+    assert y.shape == ref.shape
+    assert_close_to_truth(y, ref, ref64, "discriminator logits")
+    with pytest.raises(NotImplementedError):
+        d(x.to(dev))                                   # gradients would be needed: the backward is not built, no silent detach

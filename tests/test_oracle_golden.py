@@ -181,3 +181,22 @@ def test_training_gradients_match_reference(golden):
     (y * g.ins["dy"]).sum().backward()
     assert rel_err(y, g.outs["y"]) < 5e-6 and rel_err(x.grad, g.outs["d_x"]) < 2e-5
     assert rel_err(a.grad, g.outs["g/act.alpha"]) < 5e-5 and rel_err(b.grad, g.outs["g/act.beta"]) < 5e-5
+
+
+def test_discriminator_oracle_matches_reference(golden):
+    """Logits and autograd gradients of the reference's Discriminator class on seeded weights (fixture: seed + data) against the
+    oracle's restatement."""
+    g = golden("train_grads_discriminator")
+    sd = {k: v.clone().requires_grad_() for k, v in ref_cpu.seeded_discriminator_sd(g.meta["seed"]).items()}
+    x = g.ins["x"].clone().requires_grad_()
+    y = ref_cpu.discriminator_forward(sd, "", x)
+    assert rel_err(y, g.outs["y"]) < 1e-5
+    (y * g.ins["dy"]).sum().backward()
+    assert rel_err(x.grad, g.outs["d_x"]) < 5e-5
+    for k, ref in g.outs.items():
+        if k.startswith("g/"):
+            assert rel_err(sd[k[2:]].grad, ref) < 1e-4, k
+        elif k.startswith("proj/"):
+            p = sd[k[5:]]
+            r = torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel()))
+            assert abs(float((p.grad * r).sum()) - float(ref)) < 1e-3 * max(1.0, abs(float(ref))), k
