@@ -1334,6 +1334,8 @@ struct DLayer {
   int Cin, Cout, kw, sw, pw;
   PackedConv fwd[3];                      // per kernel row dh
   std::vector<float> w;                   // folded weight (Cout, Cin, 3, kw), kept for the training images
+  PackedConv bwd[3][2];                   // backward-data per kernel row (and per output phase for the stride-2 layers)
+  DevBuf g_dev, v_dev;                    // weight-norm parameters on the device (for d g / d v)
 };
 constexpr int kDiscLayers = 6;
 const int kDiscCfg[kDiscLayers][5] = {{1, 64, 9, 1, 4}, {64, 128, 9, 2, 4}, {128, 256, 9, 2, 4}, {256, 512, 9, 2, 4}, {512, 1024, 3, 1, 1},
@@ -1343,8 +1345,16 @@ int64_t disc_out_w(const DLayer& l, int64_t W) { return (W + 2 * l.pw - l.kw) / 
 
 struct dmel_discriminator {
   TensorStore ts;
-  bool ready = false;
+  bool ready = false, train = false, train_ready = false;
   DLayer layer[kDiscLayers];
+  struct GradSlot { std::string key; int64_t offset, numel; };
+  std::vector<GradSlot> slots;
+  int64_t grad_floats = 0;
+  int64_t slot_of(const std::string& key) const {
+    for (const auto& sl : slots)
+      if (sl.key == key) return sl.offset;
+    return -1;
+  }
 };
 
 extern "C" int dmel_discriminator_create(dmel_discriminator** out) {
@@ -1388,6 +1398,32 @@ static int disc_pack_forward(DLayer& l, const std::vector<float>& bias) {
   return DMEL_OK;
 }
 
+// backward-data images.  y[n] (+)= W_dh * x[n + dh - 1]  =>  d x[m] (+)= W_dh^T * d y[m - dh + 1]:
+//   stride 1: the same convolution with the taps reversed (kw = 2 pw + 1, so the padding is unchanged);
+//   stride 2: output phase ph of d x takes the taps dw = ph (mod 2): d x[2q + ph] = sum_t W[.., 8 - 2t - ph] d y[q + t - (2 - ph)].
+static int disc_pack_backward(DLayer& l) {
+  const int Cin = l.Cin, kw = l.kw;
+  const std::vector<float>& w = l.w;
+  for (int dh = 0; dh < 3; ++dh) {
+    auto W = [&, dh](int co, int ci, int dw) { return w[(((size_t)co * Cin + ci) * 3 + dh) * kw + dw]; };
+    if (l.sw == 1) {
+      PackDesc d;
+      d.mode = EPI_LINEAR; d.C = Cin; d.nseg = 1;
+      d.seg[0].Cin = l.Cout; d.seg[0].taps = kw; d.seg[0].dil = 1; d.seg[0].pad_left = l.pw;
+      DMEL_TRY(pack_conv(l.bwd[dh][0], d, [&](int, int row, int cc, int tap) { return W(cc, row, kw - 1 - tap); }, [&](int) { return 0.f; }));
+    } else {
+      for (int ph = 0; ph < 2; ++ph) {
+        PackDesc d;
+        d.mode = EPI_LINEAR; d.C = Cin; d.nseg = 1;
+        d.seg[0].Cin = l.Cout; d.seg[0].taps = 5 - ph; d.seg[0].dil = 1; d.seg[0].pad_left = 2 - ph;
+        DMEL_TRY(pack_conv(l.bwd[dh][ph], d, [&](int, int row, int cc, int tap) { return W(cc, row, 8 - 2 * tap - ph); },
+                           [&](int) { return 0.f; }));
+      }
+    }
+  }
+  return DMEL_OK;
+}
+
 extern "C" int dmel_discriminator_finalize(dmel_discriminator* d) {
   DMEL_CHECK_ARG(d, "NULL handle");
   for (int i = 0; i < kDiscLayers; ++i) {
@@ -1397,9 +1433,39 @@ extern "C" int dmel_discriminator_finalize(dmel_discriminator* d) {
     const HostTensor* b = d->ts.need(p + "bias", {l.Cout});
     if (!b) return DMEL_EMISSING;
     DMEL_TRY(disc_pack_forward(l, b->v));
+    if (d->train) {
+      const HostTensor* g0 = d->ts.need(p + "parametrizations.weight.original0", {l.Cout, 1, 1, 1});
+      const HostTensor* v0 = d->ts.need(p + "parametrizations.weight.original1", {l.Cout, l.Cin, 3, l.kw});
+      if (!g0 || !v0) { set_error("discriminator training needs the weight-normed form (parametrizations.weight.original0|1) of '%s'", p.c_str()); return DMEL_EMISSING; }
+      DMEL_TRY(upload_vec(l.g_dev, g0->v));
+      DMEL_TRY(upload_vec(l.v_dev, v0->v));
+      DMEL_TRY(disc_pack_backward(l));
+    }
+  }
+  if (d->train) {
+    d->slots.clear();
+    int64_t off = 0;
+    for (int i = 0; i < kDiscLayers; ++i) {
+      const DLayer& l = d->layer[i];
+      const std::string p = "blocks." + std::to_string(2 * i) + ".";
+      d->slots.push_back({p + "bias", off, l.Cout}); off += l.Cout;
+      d->slots.push_back({p + "parametrizations.weight.original0", off, l.Cout}); off += l.Cout;
+      const int64_t nw = (int64_t)l.Cout * l.Cin * 3 * l.kw;
+      d->slots.push_back({p + "parametrizations.weight.original1", off, nw}); off += nw;
+    }
+    d->grad_floats = off;
+    d->train_ready = true;
   }
   d->ts.t.clear();
   d->ready = true;
+  return DMEL_OK;
+}
+
+extern "C" int dmel_discriminator_enable_training(dmel_discriminator* d, int on) {
+  DMEL_CHECK_ARG(d, "NULL handle");
+  d->train = on != 0;
+  d->ready = false;
+  d->train_ready = false;
   return DMEL_OK;
 }
 
@@ -1492,7 +1558,7 @@ extern "C" int dmel_discriminator_forward(const dmel_discriminator* d, const flo
                                           size_t workspace_bytes, void* stream) {
   DMEL_CHECK_ARG(d && x && y && workspace, "discriminator_forward: NULL argument");
   if (!d->ready) { set_error("discriminator_forward: handle not finalized"); return DMEL_EMISSING; }
-  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0 && (int64_t)B * (H + 2) < 2000000000, "discriminator_forward: bad shape");
+  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0 && (int64_t)B * (H + 2) < 65535, "discriminator_forward: bad shape (B * (H + 2) image rows must stay below 65535)");
   const DPlan p = disc_plan(d, B, H, W, false, workspace);
   DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "discriminator_forward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
   hipStream_t st = (hipStream_t)stream;
@@ -1500,6 +1566,161 @@ extern "C" int dmel_discriminator_forward(const dmel_discriminator* d, const flo
   const int64_t Wo = p.W[kDiscLayers];
   DMEL_HIP(hipMemcpy2DAsync(y, (size_t)H * Wo * sizeof(float), p.act[kDiscLayers] + Wo, (size_t)(H + 2) * Wo * sizeof(float),
                             (size_t)H * Wo * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+  return DMEL_OK;
+}
+
+// ---- discriminator training path -------------------------------------------------------------------------------------------
+namespace {
+// per output channel: d g = <dW, v> / |v|;  d v = g / |v| * (dW - v <dW, v> / |v|^2)        (torch._weight_norm, dim 0)
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, const float* __restrict__ v,
+                                                              const float* __restrict__ g, float* __restrict__ dg, float* __restrict__ dv,
+                                                              int64_t inner) {
+  __shared__ float part[2][4];
+  const int co = blockIdx.x;
+  const float* dwr = dw + (int64_t)co * inner;
+  const float* vr = v + (int64_t)co * inner;
+  float dot = 0.f, ss = 0.f;
+  for (int64_t i = threadIdx.x; i < inner; i += 256) {
+    dot = fmaf(dwr[i], vr[i], dot);
+    ss = fmaf(vr[i], vr[i], ss);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { dot += __shfl_xor(dot, o, 64); ss += __shfl_xor(ss, o, 64); }
+  if ((threadIdx.x & 63) == 0) { part[0][threadIdx.x >> 6] = dot; part[1][threadIdx.x >> 6] = ss; }
+  __syncthreads();
+  dot = part[0][0] + part[0][1] + part[0][2] + part[0][3];
+  ss = part[1][0] + part[1][1] + part[1][2] + part[1][3];
+  const float nrm = sqrtf(ss), gg = g[co];
+  if (threadIdx.x == 0) dg[co] = dot / nrm;
+  const float k1 = gg / nrm, k2 = dot / ss;
+  for (int64_t i = threadIdx.x; i < inner; i += 256) dv[(int64_t)co * inner + i] = k1 * (dwr[i] - vr[i] * k2);
+}
+struct DTrainPlan {
+  DPlan f;
+  float *ga, *gb, *dwfold;
+  int64_t* len_in;
+  size_t bytes;
+};
+DTrainPlan disc_train_plan(const dmel_discriminator* d, int B, int H, int64_t W, void* ws) {
+  DTrainPlan t{};
+  t.f = disc_plan(d, B, H, W, true, ws);
+  Arena a(ws, (size_t)-1);
+  a.off = t.f.bytes;
+  size_t mx = 0, mw = 0;
+  for (int i = 0; i < kDiscLayers; ++i) {
+    mx = std::max(mx, (size_t)(t.f.items + 2) * d->layer[i].Cout * t.f.W[i + 1]);
+    mw = std::max(mw, (size_t)d->layer[i].Cout * d->layer[i].Cin * 3 * d->layer[i].kw);
+  }
+  mx = std::max(mx, (size_t)(t.f.items + 2) * W);
+  t.ga = a.take<float>(mx);
+  t.gb = a.take<float>(mx);
+  t.dwfold = a.take<float>(mw);
+  t.len_in = a.take<int64_t>((size_t)t.f.items);
+  t.bytes = align_up(a.off, 256);
+  return t;
+}
+}  // namespace
+
+extern "C" size_t dmel_discriminator_train_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W) {
+  if (!d || B <= 0 || H <= 0 || W <= 0) return 0;
+  return disc_train_plan(d, B, H, W, nullptr).bytes;
+}
+extern "C" int64_t dmel_discriminator_grad_floats(const dmel_discriminator* d) { return d && d->train_ready ? d->grad_floats : 0; }
+extern "C" int dmel_discriminator_grad_slot(const dmel_discriminator* d, const char* key, int64_t* offset, int64_t* numel) {
+  DMEL_CHECK_ARG(d && key && offset && numel, "discriminator_grad_slot: NULL argument");
+  if (!d->train_ready) { set_error("discriminator_grad_slot: training was not enabled before finalize"); return DMEL_EMISSING; }
+  for (const auto& sl : d->slots)
+    if (sl.key == key) { *offset = sl.offset; *numel = sl.numel; return DMEL_OK; }
+  set_error("discriminator_grad_slot: '%s' is not a parameter of the discriminator", key);
+  return DMEL_EINVAL;
+}
+
+extern "C" int dmel_discriminator_forward_train(const dmel_discriminator* d, const float* x, float* y, int B, int H, int64_t W,
+                                                void* workspace, size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(d && x && y && workspace, "discriminator_forward_train: NULL argument");
+  if (!d->ready || !d->train_ready) { set_error("discriminator_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0 && (int64_t)B * (H + 2) < 65535, "discriminator_forward_train: bad shape");
+  const DTrainPlan t = disc_train_plan(d, B, H, W, workspace);
+  DMEL_CHECK_ARG(workspace_bytes >= t.bytes, "discriminator_forward_train: workspace too small (%zu < %zu)", workspace_bytes, t.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  DMEL_TRY(disc_forward_common(d, t.f, x, B, H, W, st));
+  const int64_t Wo = t.f.W[kDiscLayers];
+  DMEL_HIP(hipMemcpy2DAsync(y, (size_t)H * Wo * sizeof(float), t.f.act[kDiscLayers] + Wo, (size_t)(H + 2) * Wo * sizeof(float),
+                            (size_t)H * Wo * sizeof(float), B, hipMemcpyDeviceToDevice, st));
+  return DMEL_OK;
+}
+
+// dy (B, H, W_out) -> dx (B, H, W) (nullable) and the parameter gradients (bias, weight-norm g and v of every layer) in `grads`
+extern "C" int dmel_discriminator_backward(const dmel_discriminator* d, const float* dy, float* dx, float* grads, int B, int H, int64_t W,
+                                           void* workspace, size_t workspace_bytes, void* stream) {
+  DMEL_CHECK_ARG(d && dy && grads && workspace, "discriminator_backward: NULL argument");
+  if (!d->ready || !d->train_ready) { set_error("discriminator_backward: enable_training + finalize first"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0, "discriminator_backward: bad shape");
+  const DTrainPlan t = disc_train_plan(d, B, H, W, workspace);
+  DMEL_CHECK_ARG(workspace_bytes >= t.bytes, "discriminator_backward: workspace too small (%zu < %zu)", workspace_bytes, t.bytes);
+  hipStream_t st = (hipStream_t)stream;
+  const DPlan& p = t.f;
+  const int Hp = H + 2;
+  const int64_t items = p.items;
+  // gradient buffers use the same padded item layout with one guard item on each side; g points at item 0
+  auto zero_buf = [&](float* base, int C, int64_t Wl) { return hipMemsetAsync(base - (size_t)C * Wl, 0, (size_t)(items + 2) * C * Wl * sizeof(float), st); };
+  float* g;                     // ga / gb are raw buffers: item 0 of a tensor starts one guard item (C * W floats) in
+  {
+    const int64_t Wo = p.W[kDiscLayers];
+    g = t.ga + Wo;
+    DMEL_HIP(zero_buf(g, 1, Wo));
+    DMEL_HIP(hipMemcpy2DAsync(g + Wo, (size_t)Hp * Wo * sizeof(float), dy, (size_t)H * Wo * sizeof(float), (size_t)H * Wo * sizeof(float), B,
+                              hipMemcpyDeviceToDevice, st));
+  }
+  bool g_is_a = true;
+  for (int i = kDiscLayers - 1; i >= 0; --i) {
+    const DLayer& l = d->layer[i];
+    const std::string pk = "blocks." + std::to_string(2 * i) + ".";
+    const int64_t Win = p.W[i], Wout = p.W[i + 1];
+    const int64_t ostr = (int64_t)l.Cout * Wout, istr = (int64_t)l.Cin * Win;
+    // g: d act[i+1] (items, Cout, Wout), zero on the pad rows.  Through the SiLU (not after the last layer), in place.
+    if (i < kDiscLayers - 1) DMEL_TRY(launch_silu_bwd(g, p.pre[i], g, items * ostr, st));
+    // bias and weight gradients
+    DMEL_TRY(launch_conv_bgrad(g, grads + d->slot_of(pk + "bias"), l.Cout, (int)items, Wout, st));
+    DMEL_HIP(hipMemsetAsync(t.dwfold, 0, (size_t)l.Cout * l.Cin * 3 * l.kw * sizeof(float), st));
+    for (int dh = 0; dh < 3; ++dh)
+      for (int dw = 0; dw < l.kw; ++dw)
+        DMEL_TRY(launch_conv_wgrad_strided(g, p.act[i] + (int64_t)(dh - 1) * istr, t.dwfold, l.Cout, l.Cin, l.sw, dw - l.pw, Wout, Win,
+                                           3 * l.kw, dh * l.kw + dw, (int)items, st));
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)l.Cout), dim3(256), 0, st, t.dwfold, l.v_dev.as<float>(), l.g_dev.as<float>(),
+                       grads + d->slot_of(pk + "parametrizations.weight.original0"),
+                       grads + d->slot_of(pk + "parametrizations.weight.original1"), (int64_t)l.Cin * 3 * l.kw);
+    DMEL_HIP(hipGetLastError());
+    if (i == 0 && !dx) break;
+    // backward-data into `other` (items, Cin, Win)
+    float* dst = (g_is_a ? t.gb : t.ga) + istr;
+    DMEL_HIP(zero_buf(dst, l.Cin, Win));
+    int64_t* lenp = i == 0 ? t.len_in : p.len[i - 1];
+    if (i == 0) {
+      hipLaunchKernelGGL(disc_len_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, t.len_in, items, Hp, Win);
+      DMEL_HIP(hipGetLastError());
+    }
+    const int order[3] = {1, 0, 2};
+    for (int k = 0; k < 3; ++k) {
+      const int dh = order[k];
+      const int nph = l.sw == 1 ? 1 : 2;
+      for (int ph = 0; ph < nph; ++ph) {
+        ConvRun r = run_1seg(g - (int64_t)(dh - 1) * ostr, l.Cout, Wout, dst, l.Cin, Win, (int)items);
+        r.out_len = lenp; r.len_div = 1;
+        r.accumulate = k > 0;
+        if (l.sw == 2) {
+          r.out_tstride = 2; r.phase_base = ph; r.Tcols = (Win - ph + 1) / 2; r.Tout = Win;
+        }
+        if (r.Tcols > 0) DMEL_TRY(launch_conv(l.bwd[dh][ph], r, st));
+      }
+    }
+    g = dst;
+    g_is_a = !g_is_a;
+  }
+  if (dx) {
+    DMEL_HIP(hipMemcpy2DAsync(dx, (size_t)H * W * sizeof(float), g + W, (size_t)Hp * W * sizeof(float), (size_t)H * W * sizeof(float), B,
+                              hipMemcpyDeviceToDevice, st));
+  }
   return DMEL_OK;
 }
 

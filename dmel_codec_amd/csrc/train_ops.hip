@@ -61,7 +61,7 @@ __global__ void silu_fwd_kernel(const float* u, float* y, int64_t total) {   // 
 }
 
 // d silu(u) / du = s (1 + u (1 - s))
-__global__ void silu_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u, float* __restrict__ du, int64_t total) {
+__global__ void silu_bwd_kernel(const float* g, const float* __restrict__ u, float* du, int64_t total) {   // du may alias g
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const float v = u[i], s = sigmoidf_(v);
     du[i] = g[i] * s * (1.f + v * (1.f - s));

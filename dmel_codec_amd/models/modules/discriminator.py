@@ -1,8 +1,8 @@
 """Mel-image discriminator on the MI355X.  Mirrors dmel_codec/models/modules/discriminator.py:6-35 (reference): six weight-normed
 Conv2d with SiLU in between, state-dict keys `blocks.{i}.bias`, `blocks.{i}.parametrizations.weight.original0|1`.  forward() runs
-the native handle (csrc/modules.hip: every (3, kw) Conv2d as three implicit-GEMM launches over padded image rows).  Inference only so
-far: its backward -- the last missing piece of training_step (codec_lit_modules.py:214-267) -- is not built, and a call that would
-need gradients raises instead of silently detaching."""
+the native handle (csrc/modules.hip: every (3, kw) Conv2d as three implicit-GEMM launches over padded image rows) and is differentiable
+through the hand-written backward (dmel_discriminator_forward_train / _backward: transposed convs per kernel row and output phase, 27
+single-tap weight-gradient GEMMs per layer, the chain through weight norm)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -13,6 +13,44 @@ from torch.nn.utils.parametrizations import weight_norm
 
 from ... import _lib
 from ._native import NativeModule
+
+
+class _DiscTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, module, x, *params):
+        L = _lib.lib()
+        B, H, W = x.shape
+        with torch.cuda.device(x.device):
+            h = module.native()
+            y = torch.empty(B, H, L.dmel_discriminator_out_frames(h, W), dtype=torch.float32, device=x.device)
+            ws = torch.empty(L.dmel_discriminator_train_workspace_bytes(h, B, H, W), dtype=torch.uint8, device=x.device)
+            _lib.check(L.dmel_discriminator_forward_train(h, x.data_ptr(), y.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
+                                                          _lib.stream_ptr()), "discriminator_forward_train")
+        ctx.module, ctx.handle, ctx.ws, ctx.shape = module, h, ws, (B, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        module, h, ws = ctx.module, ctx.handle, ctx.ws
+        if module._handle != h:
+            raise RuntimeError("discriminator parameters changed between forward and backward")
+        L = _lib.lib()
+        B, H, W = ctx.shape
+        dy = dy.float().contiguous()
+        dx = torch.empty(B, H, W, dtype=torch.float32, device=dy.device) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(dy.device):
+            flat = torch.empty(L.dmel_discriminator_grad_floats(h), dtype=torch.float32, device=dy.device)
+            _lib.check(L.dmel_discriminator_backward(h, dy.data_ptr(), _lib.ptr(dx), flat.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
+                                                     _lib.stream_ptr()), "discriminator_backward")
+        grads = []
+        off, num = C.c_int64(), C.c_int64()
+        for (key, prm), need in zip(module.named_parameters(), ctx.needs_input_grad[2:]):
+            if not need:
+                grads.append(None)
+                continue
+            _lib.check(L.dmel_discriminator_grad_slot(h, key.encode(), C.byref(off), C.byref(num)), "discriminator_grad_slot")
+            grads.append(flat[off.value:off.value + num.value].view(prm.shape))
+        return (None, dx, *grads)
 
 
 class Discriminator(NativeModule):
@@ -34,6 +72,8 @@ class Discriminator(NativeModule):
     def _create_native(self) -> int:
         h = C.c_void_p()
         _lib.check(_lib.lib().dmel_discriminator_create(C.byref(h)), "discriminator_create")
+        if getattr(self, "_want_train", False):
+            _lib.check(_lib.lib().dmel_discriminator_enable_training(h, 1), "discriminator_enable_training")
         return h.value
 
     def forward(self, x):
@@ -41,10 +81,12 @@ class Discriminator(NativeModule):
         _lib.require_cuda(x, "x")
         if x.ndim != 3:
             raise ValueError(f"expected (B, n_mels, T), got {tuple(x.shape)}")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("the discriminator's backward is not built yet (SURVEY.md 8f rank 1); call it under "
-                                      "torch.no_grad() for logits only")
         x = x.float().contiguous()
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            if not getattr(self, "_want_train", False):
+                self._want_train = True
+                self._free_native()
+            return _DiscTrainFn.apply(self, x, *list(self.parameters()))
         B, H, W = x.shape
         L = _lib.lib()
         with torch.no_grad(), torch.cuda.device(x.device):

@@ -244,6 +244,17 @@ int64_t dmel_discriminator_out_frames(const dmel_discriminator* d, int64_t W);
 size_t dmel_discriminator_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W);
 int dmel_discriminator_forward(const dmel_discriminator* d, const float* x, float* y, int B, int H, int64_t W, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* Training path (same conventions as the WaveNet's): forward_train keeps every layer's input and pre-activation in the workspace,
+ * backward returns dx (nullable) and the gradients of bias / weight-norm g (original0) / v (original1) of every layer in the flat
+ * buffer (the chain through torch._weight_norm is applied here).  enable_training requires the weight-normed form of the weights. */
+int dmel_discriminator_enable_training(dmel_discriminator* d, int on);
+size_t dmel_discriminator_train_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W);
+int64_t dmel_discriminator_grad_floats(const dmel_discriminator* d);
+int dmel_discriminator_grad_slot(const dmel_discriminator* d, const char* key, int64_t* offset, int64_t* numel);
+int dmel_discriminator_forward_train(const dmel_discriminator* d, const float* x, float* y, int B, int H, int64_t W, void* workspace,
+                                     size_t workspace_bytes, void* stream);
+int dmel_discriminator_backward(const dmel_discriminator* d, const float* dy, float* dx /*nullable*/, float* grads, int B, int H, int64_t W,
+                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Single-op entry point for the implicit-GEMM conv kernel (tests, module mirrors).
