@@ -58,6 +58,7 @@ PROTOTYPES = {
     "dmel_discriminator_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int64]),
     "dmel_discriminator_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_discriminator_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_discriminator_refresh": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), vp]),
     "dmel_discriminator_train_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int64]),
     "dmel_discriminator_grad_floats": (C.c_int64, [vp]),
     "dmel_discriminator_grad_slot": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -39,7 +39,7 @@ def bigvgan_h(name: str, **overrides) -> AttrDict:
 def build_codec(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, n_mels=100, dmel_groups=10,
                 levels=(7, 5, 5), f_min=0.0, f_max=None, residual_channels=70, encoder_layers=20, decoder_layers=20,
                 downsample_factor=(2, 2), vocoder: str | dict | None = "base_24k_100band", fsq_prebound=True,
-                dilation_cycle=4):
+                dilation_cycle=4, discriminator: bool = False, optimizer=None, lr_scheduler=None):
     """Assemble a randomly initialised VQGAN with the reference's layer shapes (config/codec/dMel_example.yaml,
     stage/pretrain.yaml): encoder WaveNet n_mels/G -> residual_channels, FSQ over G groups, decoder WaveNet
     G*residual_channels wide conditioned on the quantised latent, BigVGAN vocoder."""
@@ -67,7 +67,13 @@ def build_codec(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, 
         decoder=WaveNet(input_channels=concat, output_channels=n_mels, residual_channels=concat,
                         residual_layers=decoder_layers, dilation_cycle=dilation_cycle, condition_channels=concat),
         sampling_rate=sample_rate, dmel_groups=dmel_groups, quanlity_linear=concat, dtype="float32",
-        load_vocoder_ckpt=False)
+        load_vocoder_ckpt=False, discriminator=_discriminator() if discriminator else None, optimizer=optimizer,
+        lr_scheduler=lr_scheduler)
+
+
+def _discriminator():
+    from .models.modules.discriminator import Discriminator
+    return Discriminator()
 
 
 def oracle_cfg(codec) -> dict:

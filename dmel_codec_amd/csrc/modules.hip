@@ -1621,6 +1621,87 @@ DTrainPlan disc_train_plan(const dmel_discriminator* d, int B, int H, int64_t W,
 }
 }  // namespace
 
+namespace {
+// folded weight on the device: W[co, :] = g[co] * v[co, :] / |v[co, :]|      (torch._weight_norm, dim 0)
+__global__ __launch_bounds__(256) void weight_norm_fwd_kernel(const float* __restrict__ v, const float* __restrict__ g, float* __restrict__ w,
+                                                              int64_t inner) {
+  __shared__ float part[4];
+  const int co = blockIdx.x;
+  const float* vr = v + (int64_t)co * inner;
+  float ss = 0.f;
+  for (int64_t i = threadIdx.x; i < inner; i += 256) ss = fmaf(vr[i], vr[i], ss);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float scale = g[co] / sqrtf(part[0] + part[1] + part[2] + part[3]);
+  for (int64_t i = threadIdx.x; i < inner; i += 256) w[(int64_t)co * inner + i] = vr[i] * scale;
+}
+}  // namespace
+
+// Re-pack every weight image from the device-resident bias / weight-norm g / v (after an optimiser step); `scratch` holds the folded
+// weight of the largest layer (1024 * 512 * 9 floats).  (The host-side fold at finalize sums |v|^2 in double, this kernel in float:
+// images agree to rounding, not bitwise.)
+extern "C" int dmel_discriminator_refresh(dmel_discriminator* d, int n, const char* const* keys, const float* const* device_tensors,
+                                          void* stream) {
+  DMEL_CHECK_ARG(d && keys && device_tensors && n > 0, "discriminator_refresh: bad argument");
+  if (!d->ready) { set_error("discriminator_refresh: handle not finalized"); return DMEL_EMISSING; }
+  std::map<std::string, const float*> dev;
+  for (int i = 0; i < n; ++i) {
+    DMEL_CHECK_ARG(keys[i] && device_tensors[i], "discriminator_refresh: NULL entry %d", i);
+    dev[keys[i]] = device_tensors[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  static thread_local DevBuf fold;
+  const size_t need = (size_t)1024 * 512 * 9 * sizeof(float);
+  if (fold.bytes < need) {
+    fold.release();
+    DMEL_HIP(hipMalloc(&fold.p, need));
+    fold.bytes = need;
+  }
+  for (int i = 0; i < kDiscLayers; ++i) {
+    DLayer& l = d->layer[i];
+    const std::string p = "blocks." + std::to_string(2 * i) + ".";
+    auto get = [&](const std::string& k) -> const float* {
+      auto it = dev.find(k);
+      return it == dev.end() ? nullptr : it->second;
+    };
+    const float *b = get(p + "bias"), *g = get(p + "parametrizations.weight.original0"), *v = get(p + "parametrizations.weight.original1");
+    if (!b || !g || !v) { set_error("discriminator_refresh: tensors of '%s' were not provided", p.c_str()); return DMEL_EMISSING; }
+    const int64_t inner = (int64_t)l.Cin * 3 * l.kw;
+    float* w = fold.as<float>();
+    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((unsigned)l.Cout), dim3(256), 0, st, v, g, w, inner);
+    DMEL_HIP(hipGetLastError());
+    if (l.g_dev.p) {
+      DMEL_HIP(hipMemcpyAsync(l.g_dev.p, g, (size_t)l.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
+      DMEL_HIP(hipMemcpyAsync(l.v_dev.p, v, (size_t)l.Cout * inner * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+    for (int dh = 0; dh < 3; ++dh) {
+      {
+        RepackSrc src;
+        const int nseg = l.sw == 1 ? 1 : 2;
+        for (int sg = 0; sg < nseg; ++sg) {           // value(row = co, ci, tap) = W[co][ci][dh][sw * tap + sg]
+          src.seg[sg].w = w + dh * l.kw + sg; src.seg[sg].rs = inner; src.seg[sg].cs = 3 * l.kw; src.seg[sg].ts = l.sw;
+        }
+        src.b0 = dh == 1 ? b : nullptr;
+        DMEL_TRY(launch_repack(l.fwd[dh], src, st));
+      }
+      if (d->train_ready) {
+        const int nph = l.sw == 1 ? 1 : 2;
+        for (int ph = 0; ph < nph; ++ph) {             // value(row = ci, cc = co, tap) = W[co][ci][dh][kw-1-tap | 8 - 2 tap - ph]
+          RepackSrc src;
+          src.seg[0].rs = 3 * l.kw; src.seg[0].cs = inner;
+          if (l.sw == 1) { src.seg[0].w = w + dh * l.kw; src.seg[0].ts = 1; src.seg[0].rev = 1; }
+          else { src.seg[0].w = w + dh * l.kw + 8 - ph; src.seg[0].ts = -2; }
+          DMEL_TRY(launch_repack(l.bwd[dh][ph], src, st));
+        }
+      }
+    }
+    // the folded weight buffer is reused by the next layer: the launches above are ordered on the same stream
+  }
+  return DMEL_OK;
+}
+
 extern "C" size_t dmel_discriminator_train_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W) {
   if (!d || B <= 0 || H <= 0 || W <= 0) return 0;
   return disc_train_plan(d, B, H, W, nullptr).bytes;

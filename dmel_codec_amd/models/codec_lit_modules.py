@@ -126,6 +126,91 @@ class VQGAN(nn.Module):
         allb = avg_with_mask(mel_distance, mel_masks_float_conv)
         return (low * 0.6 + mid * 0.3 + high * 0.1) * 0.5 + allb * 0.5
 
+    # Lightning's trainer owns optimizers / schedulers / logging in the reference; the mirror is a plain nn.Module, so the few hooks
+    # training_step uses are provided here with the same names and the same effects.
+    def configure_optimizers(self):
+        """codec_lit_modules.py:121-154 (same return structure)."""
+        import itertools
+        optimizer_generator = self.optimizer_builder(itertools.chain(self.encoder.parameters(), self.quantizer.parameters(),
+                                                                     self.decoder.parameters(), self.quality_projection.parameters()))
+        optimizer_discriminator = self.optimizer_builder(self.discriminator.parameters())
+        lr_scheduler_generator = self.lr_scheduler_builder(optimizer_generator)
+        lr_scheduler_discriminator = self.lr_scheduler_builder(optimizer_discriminator)
+        return ({"optimizer": optimizer_generator,
+                 "lr_scheduler": {"scheduler": lr_scheduler_generator, "interval": "step", "name": "optimizer/generator"}},
+                {"optimizer": optimizer_discriminator,
+                 "lr_scheduler": {"scheduler": lr_scheduler_discriminator, "interval": "step", "name": "optimizer/discriminator"}})
+
+    def _trainer_state(self):
+        if getattr(self, "_opt_state", None) is None:
+            cfg = self.configure_optimizers()
+            self._opt_state = ([c["optimizer"] for c in cfg], [c["lr_scheduler"]["scheduler"] for c in cfg])
+        return self._opt_state
+
+    def optimizers(self):
+        return tuple(self._trainer_state()[0])
+
+    def lr_schedulers(self):
+        return tuple(self._trainer_state()[1])
+
+    @staticmethod
+    def manual_backward(loss):
+        loss.backward()
+
+    @staticmethod
+    def clip_gradients(optimizer, gradient_clip_val, gradient_clip_algorithm="norm"):
+        assert gradient_clip_algorithm == "norm"
+        torch.nn.utils.clip_grad_norm_([p for grp in optimizer.param_groups for p in grp["params"]], gradient_clip_val)
+
+    def log(self, name, value, **_):
+        if not hasattr(self, "logged"):
+            self.logged = {}
+        self.logged[name] = float(value.detach()) if torch.is_tensor(value) else value
+
+    def training_step(self, batch, batch_idx, noise: Optional[torch.Tensor] = None):
+        """codec_lit_modules.py:159-327, statement by statement: discriminator step (LSGAN, masked), then generator step (band-weighted
+        mel L1 + adversarial), each with manual backward / clip at 1000 / optimiser and scheduler step every `accumulate_grad` batches.
+        Every network runs on its native training path (encoder, quantiser, decoder, discriminator); `noise` (extension) injects the
+        decoder's Gaussian input.  Returns the dict of logged losses."""
+        import torch.nn.functional as F
+        if self.discriminator is None:
+            raise ValueError("Discriminator is not loaded")
+        optim_g, optim_d = self.optimizers()
+        scheduler_g, scheduler_d = self.lr_schedulers()
+        audios, audio_lengths = batch["audios"], batch["audio_lengths"]
+        gen_mel, gt_mels, mel_masks_float_conv = self.generator_forward(audios, audio_lengths, noise=noise)     # :164-211
+        batch_size = gen_mel.shape[0]
+        loss_vq = 0.0                                                                                            # :198
+        # Discriminator                                                                                          # :213-244
+        real_logits = self.discriminator(gt_mels)
+        fake_logits = self.discriminator(gen_mel.detach())
+        d_mask = F.interpolate(mel_masks_float_conv, size=(real_logits.shape[2],), mode="nearest")
+        loss_real = avg_with_mask((real_logits - 1) ** 2, d_mask)
+        loss_fake = avg_with_mask(fake_logits ** 2, d_mask)
+        loss_d = (loss_real + loss_fake) / self.accumulate_grad
+        self.log("train/discriminator/loss", loss_d * self.accumulate_grad, batch_size=batch_size)
+        self.manual_backward(loss_d)
+        if (batch_idx + 1) % self.accumulate_grad == 0:
+            self.clip_gradients(optim_d, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
+            optim_d.step()
+            optim_d.zero_grad()
+            scheduler_d.step()
+        loss_mel = self.mel_loss(gen_mel, gt_mels, mel_masks_float_conv)                                         # :246-263
+        fake_logits = self.discriminator(gen_mel)                                                                # :265-267
+        loss_adv = avg_with_mask((fake_logits - 1) ** 2, d_mask)
+        loss = (self.weight_vq * loss_vq + self.weight_mel * loss_mel + self.weight_adv * loss_adv) / self.accumulate_grad
+        self.log("train/generator/loss", loss * self.accumulate_grad, batch_size=batch_size)
+        self.log("train/generator/loss_vq", loss_vq, batch_size=batch_size)
+        self.log("train/generator/loss_mel", loss_mel, batch_size=batch_size)
+        self.log("train/generator/loss_adv", loss_adv, batch_size=batch_size)
+        self.manual_backward(loss)                                                                               # :315
+        if (batch_idx + 1) % self.accumulate_grad == 0:
+            self.clip_gradients(optim_g, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
+            optim_g.step()
+            optim_g.zero_grad()
+            scheduler_g.step()
+        return dict(self.logged)
+
     # ------------------------------------------------------------------------------ encode side
     @torch.no_grad()
     def encode_unquantized(self, audios, audio_lengths):

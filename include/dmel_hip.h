@@ -248,6 +248,8 @@ int dmel_discriminator_forward(const dmel_discriminator* d, const float* x, floa
  * backward returns dx (nullable) and the gradients of bias / weight-norm g (original0) / v (original1) of every layer in the flat
  * buffer (the chain through torch._weight_norm is applied here).  enable_training requires the weight-normed form of the weights. */
 int dmel_discriminator_enable_training(dmel_discriminator* d, int on);
+/* as dmel_wavenet_refresh (keys: blocks.{i}.bias, ...original0, ...original1); the weight-norm fold runs on the device */
+int dmel_discriminator_refresh(dmel_discriminator* d, int n, const char* const* keys, const float* const* device_tensors, void* stream);
 size_t dmel_discriminator_train_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W);
 int64_t dmel_discriminator_grad_floats(const dmel_discriminator* d);
 int dmel_discriminator_grad_slot(const dmel_discriminator* d, const char* key, int64_t* offset, int64_t* numel);
