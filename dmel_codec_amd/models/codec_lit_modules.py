@@ -162,6 +162,36 @@ class VQGAN(nn.Module):
         assert gradient_clip_algorithm == "norm"
         torch.nn.utils.clip_grad_norm_([p for grp in optimizer.param_groups for p in grp["params"]], gradient_clip_val)
 
+    @staticmethod
+    def sync_gradients(optimizer, bucket_bytes: int = 64 << 20):
+        """The exchange step of data-parallel training: average the gradients of `optimizer`'s parameters over the ranks of the default
+        process group (RCCL on the GPUs: backend "nccl"), as Lightning's DDP does during manual_backward in the reference
+        (train_codec.py:49-55; SURVEY.md section 8(e): G side 438 MB + D side 37.5 MB in fp32, twice per step).  Gradients are
+        flattened into buckets of `bucket_bytes` (xGMI rings are per-link bound: few, large messages) and all-reduced in place.
+        No-op without an initialised process group or with a single rank."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return
+        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+        world = dist.get_world_size()
+        grads = [p.grad for grp in optimizer.param_groups for p in grp["params"] if p.grad is not None]
+        bucket, size = [], 0
+        buckets = []
+        for g in grads:
+            bucket.append(g)
+            size += g.numel() * g.element_size()
+            if size >= bucket_bytes:
+                buckets.append(bucket)
+                bucket, size = [], 0
+        if bucket:
+            buckets.append(bucket)
+        for bk in buckets:
+            flat = _flatten_dense_tensors(bk)
+            dist.all_reduce(flat)
+            flat.div_(world)
+            for g, r in zip(bk, _unflatten_dense_tensors(flat, bk)):
+                g.copy_(r)
+
     def log(self, name, value, **_):
         if not hasattr(self, "logged"):
             self.logged = {}
@@ -191,6 +221,7 @@ class VQGAN(nn.Module):
         self.log("train/discriminator/loss", loss_d * self.accumulate_grad, batch_size=batch_size)
         self.manual_backward(loss_d)
         if (batch_idx + 1) % self.accumulate_grad == 0:
+            self.sync_gradients(optim_d)
             self.clip_gradients(optim_d, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
             optim_d.step()
             optim_d.zero_grad()
@@ -205,6 +236,7 @@ class VQGAN(nn.Module):
         self.log("train/generator/loss_adv", loss_adv, batch_size=batch_size)
         self.manual_backward(loss)                                                                               # :315
         if (batch_idx + 1) % self.accumulate_grad == 0:
+            self.sync_gradients(optim_g)
             self.clip_gradients(optim_g, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
             optim_g.step()
             optim_g.zero_grad()
