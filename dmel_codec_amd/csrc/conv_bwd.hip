@@ -29,6 +29,9 @@ struct WgArgs {
   // strided form (k2s2 conv / transposed conv): x[b, ci, t * xstride + xoff] of rows of length Tx; the result of the single
   // launch tap goes to dw[(co * Cin + ci) * taps_out + tap_out]
   int xstride, xoff, Tx, taps_out, tap_out;
+  // short rows (T <= 32: the deep discriminator layers have 12-24 frames per image row): ipc = 64 / T batch items share one staged
+  // 64-sample step, lane -> (item lane / T, sample lane % T); 1 = one item per step
+  int ipc;
 };
 
 // grid (ceil(Cin/64), ceil(Cout/64), taps * slices); 256 threads = 2 x 2 waves of 32 x 32
@@ -44,11 +47,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  const int total = a.B * a.chunks_per_item;
+  const int total = a.ipc > 1 ? (a.B + a.ipc - 1) / a.ipc : a.B * a.chunks_per_item;
   const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
   const int r31 = lane & 31, h = lane >> 5;
+  const int lane_item = a.ipc > 1 ? lane / a.T : 0, lane_t = a.ipc > 1 ? lane - lane_item * a.T : lane;
   for (int c = c_begin; c < c_end; ++c) {
-    const int b = c / a.chunks_per_item, t0 = (c - b * a.chunks_per_item) * kWgK;
+    int b, t0;
+    bool lane_ok = true;
+    if (a.ipc > 1) {                     // c indexes groups of ipc items; every lane has its own item
+      b = c * a.ipc + lane_item;
+      t0 = 0;
+      lane_ok = lane_item < a.ipc && b < a.B;
+      b = min(b, a.B - 1);
+    } else {
+      b = c / a.chunks_per_item;
+      t0 = (c - b * a.chunks_per_item) * kWgK;
+    }
     const float* dyb = a.dy + (int64_t)b * a.Cout * a.T;
     const float* xb = a.x + (int64_t)b * a.Cin * a.Tx;
     // stage dy[co0 .. co0+63][t0 .. t0+63] and x[ci0 .. ci0+63][t0+shift ..]: one 256-byte row segment per wave and pass
@@ -56,9 +70,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = wave + 4 * i;
-      const int t = t0 + lane, tx = t * a.xstride + a.xoff + shift;
+      const int t = t0 + lane_t, tx = t * a.xstride + a.xoff + shift;
       const int co = co0 + row, ci = ci0 + row;
-      const bool okd = co < a.Cout && t < a.T, okx = ci < a.Cin && t < a.T && tx >= 0 && tx < a.Tx;
+      const bool okd = lane_ok && co < a.Cout && t < a.T, okx = lane_ok && ci < a.Cin && t < a.T && tx >= 0 && tx < a.Tx;
       const float d = dyb[(int64_t)min(co, a.Cout - 1) * a.T + min(t, a.T - 1)];
       const float v = xb[(int64_t)min(ci, a.Cin - 1) * a.Tx + min(max(tx, 0), a.Tx - 1)];
       vd[i] = okd ? d : 0.f;
@@ -113,8 +127,9 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   a.Cout = Cout; a.Cin = Cin; a.taps = taps; a.dil = dil; a.pad = dil * (taps - 1) / 2; a.B = B; a.T = (int)T;
   a.xstride = 1; a.xoff = 0; a.Tx = (int)T; a.taps_out = taps; a.tap_out = 0;
   a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
+  a.ipc = T <= 32 ? (int)(kWgK / T) : 1;
   const int tiles = ((Cin + kWgTile - 1) / kWgTile) * ((Cout + kWgTile - 1) / kWgTile) * taps;
-  const int total = B * a.chunks_per_item;
+  const int total = a.ipc > 1 ? (B + a.ipc - 1) / a.ipc : B * a.chunks_per_item;
   // enough K slices to fill the chip (~8 workgroups per CU), each at least 8 staged steps long
   int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
   slices = std::min(slices, 65535 / std::max(1, taps));
@@ -146,8 +161,9 @@ int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, i
   a.Cout = Crows; a.Cin = Ccols; a.taps = 1; a.dil = 1; a.pad = 0; a.B = B; a.T = (int)T;
   a.xstride = xstride; a.xoff = xoff; a.Tx = (int)Tx; a.taps_out = taps_out; a.tap_out = tap_out;
   a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
+  a.ipc = T <= 32 ? (int)(kWgK / T) : 1;
   const int tiles = ((Ccols + kWgTile - 1) / kWgTile) * ((Crows + kWgTile - 1) / kWgTile);
-  const int total = B * a.chunks_per_item;
+  const int total = a.ipc > 1 ? (B + a.ipc - 1) / a.ipc : B * a.chunks_per_item;
   int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
   slices = std::min(slices, 65535);
   a.slices = slices;
