@@ -35,6 +35,7 @@ struct WgArgs {
 };
 
 // grid (ceil(Cin/64), ceil(Cout/64), taps * slices); 256 threads = 2 x 2 waves of 32 x 32
+template <bool PACK>      // PACK: several short batch items per staged step (per-lane item index); otherwise the item is wave-uniform
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   __shared__ float dys[kWgTile * kWgPitch];
   __shared__ float xs[kWgTile * kWgPitch];
@@ -47,14 +48,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  const int total = a.ipc > 1 ? (a.B + a.ipc - 1) / a.ipc : a.B * a.chunks_per_item;
+  const int total = PACK ? (a.B + a.ipc - 1) / a.ipc : a.B * a.chunks_per_item;
   const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
   const int r31 = lane & 31, h = lane >> 5;
-  const int lane_item = a.ipc > 1 ? lane / a.T : 0, lane_t = a.ipc > 1 ? lane - lane_item * a.T : lane;
+  const int lane_item = PACK ? lane / a.T : 0, lane_t = PACK ? lane - lane_item * a.T : lane;
   for (int c = c_begin; c < c_end; ++c) {
     int b, t0;
     bool lane_ok = true;
-    if (a.ipc > 1) {                     // c indexes groups of ipc items; every lane has its own item
+    if (PACK) {                          // c indexes groups of ipc items; every lane has its own item
       b = c * a.ipc + lane_item;
       t0 = 0;
       lane_ok = lane_item < a.ipc && b < a.B;
@@ -139,7 +140,8 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   dim3 grid((unsigned)((Cin + kWgTile - 1) / kWgTile), (unsigned)((Cout + kWgTile - 1) / kWgTile), (unsigned)(taps * slices));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Cout * Cin * taps, 0.0);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, a);
+    if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
   }
   DMEL_HIP(hipGetLastError());
   if (db) {
@@ -171,7 +173,8 @@ int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, i
   dim3 grid((unsigned)((Ccols + kWgTile - 1) / kWgTile), (unsigned)((Crows + kWgTile - 1) / kWgTile), (unsigned)slices);
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols, 0.0);
-    hipLaunchKernelGGL(conv_wgrad_kernel, grid, dim3(256), 0, st, a);
+    if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
