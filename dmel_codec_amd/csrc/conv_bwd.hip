@@ -154,25 +154,25 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
 // One tap of a stride-s convolution / transposed convolution: dw[(r * Ccols + c) * taps_out + tap_out] (+)= sum_{b,t} rows[b, r, t] *
 // cols[b, c, t * xstride + xoff]; rows (B, Crows, T), cols (B, Ccols, Tx).  The caller zeroes dw once before the taps.
 int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, int Crows, int Ccols, int xstride, int xoff, int64_t T,
-                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t st) {
+                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t st, int taps) {
   DMEL_CHECK_ARG(rows && cols && dw, "conv_wgrad_strided: NULL argument");
   DMEL_CHECK_ARG(B > 0 && T > 0 && Tx > 0 && Tx < ((int64_t)1 << 30) && Crows > 0 && Ccols > 0 && xstride > 0 && taps_out > 0 &&
-                     tap_out >= 0 && tap_out < taps_out, "conv_wgrad_strided: bad shape");
+                     tap_out >= 0 && taps > 0 && tap_out + taps <= taps_out, "conv_wgrad_strided: bad shape");
   WgArgs a;
   a.dy = rows; a.x = cols; a.dw = dw;
-  a.Cout = Crows; a.Cin = Ccols; a.taps = 1; a.dil = 1; a.pad = 0; a.B = B; a.T = (int)T;
+  a.Cout = Crows; a.Cin = Ccols; a.taps = taps; a.dil = 1; a.pad = 0; a.B = B; a.T = (int)T;
   a.xstride = xstride; a.xoff = xoff; a.Tx = (int)Tx; a.taps_out = taps_out; a.tap_out = tap_out;
   a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
   a.ipc = T <= 32 ? (int)(kWgK / T) : 1;
   const int tiles = ((Ccols + kWgTile - 1) / kWgTile) * ((Crows + kWgTile - 1) / kWgTile);
   const int total = a.ipc > 1 ? (B + a.ipc - 1) / a.ipc : B * a.chunks_per_item;
-  int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
-  slices = std::min(slices, 65535);
+  int slices = std::max(1, std::min((2048 + tiles * taps - 1) / (tiles * taps), (total + 7) / 8));
+  slices = std::min(slices, 65535 / taps);
   a.slices = slices;
   a.chunks_per_slice = (total + slices - 1) / slices;
-  dim3 grid((unsigned)((Ccols + kWgTile - 1) / kWgTile), (unsigned)((Crows + kWgTile - 1) / kWgTile), (unsigned)slices);
+  dim3 grid((unsigned)((Ccols + kWgTile - 1) / kWgTile), (unsigned)((Crows + kWgTile - 1) / kWgTile), (unsigned)(slices * taps));
   {
-    ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols, 0.0);
+    ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols * taps, 0.0);
     if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
   }

@@ -1470,77 +1470,138 @@ extern "C" int dmel_discriminator_enable_training(dmel_discriminator* d, int on)
 }
 
 namespace {
+// Flattened image layout.  An activation (B, C, H, W) is stored as B items of C rows of (H + 2) * P floats: image row h sits at
+// [(h + 1) * P, (h + 1) * P + W), the two pad rows and the P - W gap columns of every row are zero.  With that, a kernel row dh of the
+// 3 x kw convolution is a 1-D convolution over the flat axis of the same buffer displaced by (dh - 1) * P floats (horizontal taps that
+// leave the image land in the zero gap, vertical ones in a zero pad row), so every launch sees 32 long items instead of B * (H + 2)
+// rows of 12-94 frames and the column tiles are full.  A stride-2 layer halves the pitch: flat 2 n + dw - 4 <-> (h, 2 w + dw - 4).
+// Outputs are computed on the whole flat axis; the SiLU pass that follows rewrites pads and gaps with zeros.
 struct DPlan {
-  float* act[kDiscLayers + 1];        // act[0]: padded input image; act[i+1]: output of layer i (after SiLU for i < 5)
+  float* act[kDiscLayers + 1];        // act[0]: embedded input image; act[i+1]: output of layer i (after SiLU for i < 5)
   float* pre[kDiscLayers];            // pre-activation of layer i (training keeps it; inference aliases act[i+1])
-  int64_t* len[kDiscLayers];          // per-item valid output length of layer i (0 on the pad rows)
-  int64_t W[kDiscLayers + 1];
-  int64_t items;
+  int64_t W[kDiscLayers + 1], P[kDiscLayers + 1];     // valid width and row pitch of act[i]
+  int Hp;
+  int64_t guard;                      // floats in front of / behind every buffer that displaced reads may touch
   size_t bytes;
 };
-// every activation buffer has one guard item in front and behind (rows -1 and B*(H+2) are read by the dh = 0 / 2 launches)
+int64_t disc_pitch0(const dmel_discriminator* d, int64_t W) {
+  for (int64_t P0 = (W + 4 + 63) / 64 * 64;; P0 += 64) {
+    int64_t w = W, P = P0;
+    bool ok = true;
+    for (int i = 0; i < kDiscLayers && ok; ++i) {
+      const DLayer& l = d->layer[i];
+      ok = P - w >= l.pw;                                   // forward taps of layer i over act[i]
+      w = disc_out_w(l, w);
+      if (l.sw == 2) P /= 2;
+      ok = ok && P - w >= (l.sw == 2 ? 2 : l.pw);           // backward-data taps of layer i over d act[i+1]
+    }
+    if (ok) return P0;
+  }
+}
 DPlan disc_plan(const dmel_discriminator* d, int B, int H, int64_t W, bool train, void* ws) {
   DPlan p{};
   Arena a(ws, (size_t)-1);
-  p.items = (int64_t)B * (H + 2);
-  p.W[0] = W;
-  for (int i = 0; i < kDiscLayers; ++i) p.W[i + 1] = disc_out_w(d->layer[i], p.W[i]);
-  auto buf = [&](int C, int64_t Wl) { return a.take<float>((size_t)(p.items + 2) * C * Wl) + (size_t)C * Wl; };
-  p.act[0] = buf(1, W);
+  p.Hp = H + 2;
+  p.W[0] = W; p.P[0] = disc_pitch0(d, W);
   for (int i = 0; i < kDiscLayers; ++i) {
-    p.act[i + 1] = buf(d->layer[i].Cout, p.W[i + 1]);
-    p.pre[i] = (train && i < kDiscLayers - 1) ? buf(d->layer[i].Cout, p.W[i + 1]) : p.act[i + 1];
-    p.len[i] = a.take<int64_t>((size_t)p.items);
+    p.W[i + 1] = disc_out_w(d->layer[i], p.W[i]);
+    p.P[i + 1] = p.P[i] / d->layer[i].sw;
+  }
+  p.guard = p.P[0] + 64;
+  auto buf = [&](int C, int64_t P) { return a.take<float>((size_t)B * C * p.Hp * P + 2 * p.guard) + p.guard; };
+  p.act[0] = buf(1, p.P[0]);
+  for (int i = 0; i < kDiscLayers; ++i) {
+    p.act[i + 1] = buf(d->layer[i].Cout, p.P[i + 1]);
+    p.pre[i] = (train && i < kDiscLayers - 1) ? buf(d->layer[i].Cout, p.P[i + 1]) : p.act[i + 1];
   }
   p.bytes = align_up(a.off, 256);
   return p;
 }
-__global__ void disc_len_kernel(int64_t* len, int64_t items, int Hp, int64_t W) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i < items) {
-    const int h = (int)(i % Hp);
-    len[i] = (h == 0 || h == Hp - 1) ? 0 : W;
-  }
+__device__ __forceinline__ bool disc_valid(int col, int Hp, int P, int Wv) {
+  const int h = col / P, w = col - h * P;
+  return h >= 1 && h < Hp - 1 && w < Wv;
 }
+// grid (rows = B * C, ceil(Hp * P / 256)); y may alias u
+__global__ __launch_bounds__(256) void disc_silu_fwd_kernel(const float* u, float* y, int Hp, int P, int Wv) {
+  const int col = blockIdx.y * 256 + threadIdx.x, len = Hp * P;
+  if (col >= len) return;
+  const int64_t i = (int64_t)blockIdx.x * len + col;
+  const float v = u[i];
+  y[i] = disc_valid(col, Hp, P, Wv) ? v / (1.f + __expf(-v)) : 0.f;
+}
+// g <- g * silu'(u) on the image, 0 on pads and gaps (in place)
+__global__ __launch_bounds__(256) void disc_silu_bwd_kernel(float* g, const float* __restrict__ u, int Hp, int P, int Wv) {
+  const int col = blockIdx.y * 256 + threadIdx.x, len = Hp * P;
+  if (col >= len) return;
+  const int64_t i = (int64_t)blockIdx.x * len + col;
+  const float v = u[i], sg = 1.f / (1.f + __expf(-v));
+  g[i] = disc_valid(col, Hp, P, Wv) ? g[i] * sg * (1.f + v * (1.f - sg)) : 0.f;
+}
+// compact (B, H, Wv) -> flat (B, 1, Hp, P), zeros on pads and gaps; grid (B, ceil(Hp * P / 256))
+__global__ __launch_bounds__(256) void disc_embed_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hp, int P, int Wv) {
+  const int col = blockIdx.y * 256 + threadIdx.x, len = Hp * P;
+  if (col >= len) return;
+  const int h = col / P, w = col - h * P;
+  const bool ok = h >= 1 && h < Hp - 1 && w < Wv;
+  dst[(int64_t)blockIdx.x * len + col] = ok ? src[((int64_t)blockIdx.x * (Hp - 2) + (h - 1)) * Wv + w] : 0.f;
+}
+// flat (B, 1, Hp, P) -> compact (B, H, Wv); grid (B, ceil(H * Wv / 256))
+__global__ __launch_bounds__(256) void disc_extract_kernel(const float* __restrict__ src, float* __restrict__ dst, int Hp, int P, int Wv) {
+  const int j = blockIdx.y * 256 + threadIdx.x, n = (Hp - 2) * Wv;
+  if (j >= n) return;
+  const int h = j / Wv, w = j - h * Wv;
+  dst[(int64_t)blockIdx.x * n + j] = src[(int64_t)blockIdx.x * Hp * P + (int64_t)(h + 1) * P + w];
+}
+inline dim3 disc_grid(int64_t rows, int64_t len) { return dim3((unsigned)rows, (unsigned)((len + 255) / 256)); }
+
 // layer i forward into `out` (pre-activation): three launches, centre row first
-int disc_layer_forward(const dmel_discriminator* d, const DPlan& p, int i, const float* in, float* out, hipStream_t st) {
+int disc_layer_forward(const dmel_discriminator* d, const DPlan& p, int i, int B, const float* in, float* out, hipStream_t st) {
   const DLayer& l = d->layer[i];
-  const int64_t Win = p.W[i], Wout = p.W[i + 1], istr = (int64_t)l.Cin * Win;
+  const int64_t Tin = p.Hp * p.P[i], Tout = p.Hp * p.P[i + 1];
   const int order[3] = {1, 0, 2};
   for (int k = 0; k < 3; ++k) {
     const int dh = order[k];
     ConvRun r;
     const int nseg = l.sw == 1 ? 1 : 2;
     for (int sg = 0; sg < nseg; ++sg) {
-      r.seg[sg].x = in + (int64_t)(dh - 1) * istr; r.seg[sg].bstride = istr; r.seg[sg].cstride = Win; r.seg[sg].Tin = Win;
+      r.seg[sg].x = in + (int64_t)(dh - 1) * p.P[i]; r.seg[sg].bstride = l.Cin * Tin; r.seg[sg].cstride = Tin; r.seg[sg].Tin = Tin;
     }
-    r.B = (int)p.items; r.Tcols = Wout; r.y = out; r.y_bs = (int64_t)l.Cout * Wout; r.y_cs = Wout; r.Tout = Wout;
-    r.out_len = p.len[i]; r.len_div = 1;
+    r.B = B; r.Tcols = Tout; r.y = out; r.y_bs = l.Cout * Tout; r.y_cs = Tout; r.Tout = Tout;
     r.accumulate = k > 0;
     DMEL_TRY(launch_conv(l.fwd[dh], r, st));
   }
   return DMEL_OK;
 }
 int disc_forward_common(const dmel_discriminator* d, const DPlan& p, const float* x, int B, int H, int64_t W, hipStream_t st) {
-  const int Hp = H + 2;
-  // zero everything once: pad rows, guard items (act[0] only needs its pads, the rest is overwritten, but one memset is simpler)
-  DMEL_HIP(hipMemsetAsync(p.act[0] - W, 0, (size_t)(p.items + 2) * W * sizeof(float), st));
-  DMEL_HIP(hipMemcpy2DAsync(p.act[0] + W, (size_t)Hp * W * sizeof(float), x, (size_t)H * W * sizeof(float), (size_t)H * W * sizeof(float), B,
-                            hipMemcpyDeviceToDevice, st));
+  // displaced reads run up to one row pitch past either end of an activation buffer: those guards must hold finite values
+  auto zero_guards = [&](float* base, int C, int64_t P) -> hipError_t {
+    hipError_t e = hipMemsetAsync(base - p.guard, 0, (size_t)p.guard * sizeof(float), st);
+    if (e != hipSuccess) return e;
+    return hipMemsetAsync(base + (size_t)B * C * p.Hp * P, 0, (size_t)p.guard * sizeof(float), st);
+  };
+  DMEL_HIP(zero_guards(p.act[0], 1, p.P[0]));
+  hipLaunchKernelGGL(disc_embed_kernel, disc_grid(B, p.Hp * p.P[0]), dim3(256), 0, st, x, p.act[0], p.Hp, (int)p.P[0], (int)W);
+  DMEL_HIP(hipGetLastError());
   for (int i = 0; i < kDiscLayers; ++i) {
     const DLayer& l = d->layer[i];
-    const size_t n = (size_t)(p.items + 2) * l.Cout * p.W[i + 1];
-    DMEL_HIP(hipMemsetAsync(p.pre[i] - (size_t)l.Cout * p.W[i + 1], 0, n * sizeof(float), st));      // guards of the pre-activation buffer
-    hipLaunchKernelGGL(disc_len_kernel, dim3((unsigned)((p.items + 255) / 256)), dim3(256), 0, st, p.len[i], p.items, Hp, p.W[i + 1]);
-    DMEL_HIP(hipGetLastError());
-    DMEL_TRY(disc_layer_forward(d, p, i, p.act[i], p.pre[i], st));
+    DMEL_TRY(disc_layer_forward(d, p, i, B, p.act[i], p.pre[i], st));
     if (i < kDiscLayers - 1) {
-      if (p.pre[i] != p.act[i + 1])
-        DMEL_HIP(hipMemsetAsync(p.act[i + 1] - (size_t)l.Cout * p.W[i + 1], 0, n * sizeof(float), st));
-      DMEL_TRY(launch_silu_fwd(p.pre[i], p.act[i + 1], (int64_t)p.items * l.Cout * p.W[i + 1], st));   // silu(0) = 0: pads stay zero
+      DMEL_HIP(zero_guards(p.act[i + 1], l.Cout, p.P[i + 1]));
+      hipLaunchKernelGGL(disc_silu_fwd_kernel, disc_grid((int64_t)B * l.Cout, p.Hp * p.P[i + 1]), dim3(256), 0, st, p.pre[i], p.act[i + 1], p.Hp,
+                         (int)p.P[i + 1], (int)p.W[i + 1]);
+      DMEL_HIP(hipGetLastError());
     }
   }
   return DMEL_OK;
+}
+int disc_extract(const float* flat, float* compact, int B, int Hp, int64_t P, int64_t Wv, hipStream_t st) {
+  hipLaunchKernelGGL(disc_extract_kernel, disc_grid(B, (int64_t)(Hp - 2) * Wv), dim3(256), 0, st, flat, compact, Hp, (int)P, (int)Wv);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+bool disc_shape_ok(const dmel_discriminator* d, int B, int H, int64_t W) {
+  if (B <= 0 || H <= 0 || W <= 0 || (int64_t)B * 1024 >= ((int64_t)1 << 31)) return false;
+  return (int64_t)(H + 2) * disc_pitch0(d, W) < ((int64_t)1 << 23);          // flat rows stay far inside the kernels' 32-bit offsets
 }
 }  // namespace
 
@@ -1558,15 +1619,12 @@ extern "C" int dmel_discriminator_forward(const dmel_discriminator* d, const flo
                                           size_t workspace_bytes, void* stream) {
   DMEL_CHECK_ARG(d && x && y && workspace, "discriminator_forward: NULL argument");
   if (!d->ready) { set_error("discriminator_forward: handle not finalized"); return DMEL_EMISSING; }
-  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0 && (int64_t)B * (H + 2) < 65535, "discriminator_forward: bad shape (B * (H + 2) image rows must stay below 65535)");
+  DMEL_CHECK_ARG(disc_shape_ok(d, B, H, W), "discriminator_forward: bad shape");
   const DPlan p = disc_plan(d, B, H, W, false, workspace);
   DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "discriminator_forward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
   hipStream_t st = (hipStream_t)stream;
   DMEL_TRY(disc_forward_common(d, p, x, B, H, W, st));
-  const int64_t Wo = p.W[kDiscLayers];
-  DMEL_HIP(hipMemcpy2DAsync(y, (size_t)H * Wo * sizeof(float), p.act[kDiscLayers] + Wo, (size_t)(H + 2) * Wo * sizeof(float),
-                            (size_t)H * Wo * sizeof(float), B, hipMemcpyDeviceToDevice, st));
-  return DMEL_OK;
+  return disc_extract(p.act[kDiscLayers], y, B, p.Hp, p.P[kDiscLayers], p.W[kDiscLayers], st);
 }
 
 // ---- discriminator training path -------------------------------------------------------------------------------------------
@@ -1597,8 +1655,7 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
 }
 struct DTrainPlan {
   DPlan f;
-  float *ga, *gb, *dwfold;
-  int64_t* len_in;
+  float *ga, *gb, *dwfold;            // two gradient buffers in the flat layout (ping-pong down the layers), folded-weight gradient
   size_t bytes;
 };
 DTrainPlan disc_train_plan(const dmel_discriminator* d, int B, int H, int64_t W, void* ws) {
@@ -1606,16 +1663,14 @@ DTrainPlan disc_train_plan(const dmel_discriminator* d, int B, int H, int64_t W,
   t.f = disc_plan(d, B, H, W, true, ws);
   Arena a(ws, (size_t)-1);
   a.off = t.f.bytes;
-  size_t mx = 0, mw = 0;
+  size_t mx = (size_t)B * t.f.Hp * t.f.P[0], mw = 0;
   for (int i = 0; i < kDiscLayers; ++i) {
-    mx = std::max(mx, (size_t)(t.f.items + 2) * d->layer[i].Cout * t.f.W[i + 1]);
+    mx = std::max(mx, (size_t)B * d->layer[i].Cout * t.f.Hp * t.f.P[i + 1]);
     mw = std::max(mw, (size_t)d->layer[i].Cout * d->layer[i].Cin * 3 * d->layer[i].kw);
   }
-  mx = std::max(mx, (size_t)(t.f.items + 2) * W);
-  t.ga = a.take<float>(mx);
-  t.gb = a.take<float>(mx);
+  t.ga = a.take<float>(mx + 2 * t.f.guard) + t.f.guard;
+  t.gb = a.take<float>(mx + 2 * t.f.guard) + t.f.guard;
   t.dwfold = a.take<float>(mw);
-  t.len_in = a.take<int64_t>((size_t)t.f.items);
   t.bytes = align_up(a.off, 256);
   return t;
 }
@@ -1720,15 +1775,12 @@ extern "C" int dmel_discriminator_forward_train(const dmel_discriminator* d, con
                                                 void* workspace, size_t workspace_bytes, void* stream) {
   DMEL_CHECK_ARG(d && x && y && workspace, "discriminator_forward_train: NULL argument");
   if (!d->ready || !d->train_ready) { set_error("discriminator_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
-  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0 && (int64_t)B * (H + 2) < 65535, "discriminator_forward_train: bad shape");
+  DMEL_CHECK_ARG(disc_shape_ok(d, B, H, W), "discriminator_forward_train: bad shape");
   const DTrainPlan t = disc_train_plan(d, B, H, W, workspace);
   DMEL_CHECK_ARG(workspace_bytes >= t.bytes, "discriminator_forward_train: workspace too small (%zu < %zu)", workspace_bytes, t.bytes);
   hipStream_t st = (hipStream_t)stream;
   DMEL_TRY(disc_forward_common(d, t.f, x, B, H, W, st));
-  const int64_t Wo = t.f.W[kDiscLayers];
-  DMEL_HIP(hipMemcpy2DAsync(y, (size_t)H * Wo * sizeof(float), t.f.act[kDiscLayers] + Wo, (size_t)(H + 2) * Wo * sizeof(float),
-                            (size_t)H * Wo * sizeof(float), B, hipMemcpyDeviceToDevice, st));
-  return DMEL_OK;
+  return disc_extract(t.f.act[kDiscLayers], y, B, t.f.Hp, t.f.P[kDiscLayers], t.f.W[kDiscLayers], st);
 }
 
 // dy (B, H, W_out) -> dx (B, H, W) (nullable) and the parameter gradients (bias, weight-norm g and v of every layer) in `grads`
@@ -1736,72 +1788,61 @@ extern "C" int dmel_discriminator_backward(const dmel_discriminator* d, const fl
                                            void* workspace, size_t workspace_bytes, void* stream) {
   DMEL_CHECK_ARG(d && dy && grads && workspace, "discriminator_backward: NULL argument");
   if (!d->ready || !d->train_ready) { set_error("discriminator_backward: enable_training + finalize first"); return DMEL_EMISSING; }
-  DMEL_CHECK_ARG(B > 0 && H > 0 && W > 0, "discriminator_backward: bad shape");
+  DMEL_CHECK_ARG(disc_shape_ok(d, B, H, W), "discriminator_backward: bad shape");
   const DTrainPlan t = disc_train_plan(d, B, H, W, workspace);
   DMEL_CHECK_ARG(workspace_bytes >= t.bytes, "discriminator_backward: workspace too small (%zu < %zu)", workspace_bytes, t.bytes);
   hipStream_t st = (hipStream_t)stream;
   const DPlan& p = t.f;
-  const int Hp = H + 2;
-  const int64_t items = p.items;
-  // gradient buffers use the same padded item layout with one guard item on each side; g points at item 0
-  auto zero_buf = [&](float* base, int C, int64_t Wl) { return hipMemsetAsync(base - (size_t)C * Wl, 0, (size_t)(items + 2) * C * Wl * sizeof(float), st); };
-  float* g;                     // ga / gb are raw buffers: item 0 of a tensor starts one guard item (C * W floats) in
-  {
-    const int64_t Wo = p.W[kDiscLayers];
-    g = t.ga + Wo;
-    DMEL_HIP(zero_buf(g, 1, Wo));
-    DMEL_HIP(hipMemcpy2DAsync(g + Wo, (size_t)Hp * Wo * sizeof(float), dy, (size_t)H * Wo * sizeof(float), (size_t)H * Wo * sizeof(float), B,
-                              hipMemcpyDeviceToDevice, st));
-  }
+  const int Hp = p.Hp;
+  // gradients live in the flat layout of the activation they belong to.  Their guards are only ever multiplied into pad / gap outputs,
+  // which the SiLU backward pass rewrites with zeros, but they are cleared once so that every read is of defined memory.
+  DMEL_HIP(hipMemsetAsync(t.ga - p.guard, 0, (size_t)p.guard * sizeof(float), st));
+  DMEL_HIP(hipMemsetAsync(t.gb - p.guard, 0, (size_t)p.guard * sizeof(float), st));
+  float* g = t.ga;
+  hipLaunchKernelGGL(disc_embed_kernel, disc_grid(B, Hp * p.P[kDiscLayers]), dim3(256), 0, st, dy, g, Hp, (int)p.P[kDiscLayers],
+                     (int)p.W[kDiscLayers]);
+  DMEL_HIP(hipGetLastError());
   bool g_is_a = true;
   for (int i = kDiscLayers - 1; i >= 0; --i) {
     const DLayer& l = d->layer[i];
     const std::string pk = "blocks." + std::to_string(2 * i) + ".";
-    const int64_t Win = p.W[i], Wout = p.W[i + 1];
-    const int64_t ostr = (int64_t)l.Cout * Wout, istr = (int64_t)l.Cin * Win;
-    // g: d act[i+1] (items, Cout, Wout), zero on the pad rows.  Through the SiLU (not after the last layer), in place.
-    if (i < kDiscLayers - 1) DMEL_TRY(launch_silu_bwd(g, p.pre[i], g, items * ostr, st));
-    // bias and weight gradients
-    DMEL_TRY(launch_conv_bgrad(g, grads + d->slot_of(pk + "bias"), l.Cout, (int)items, Wout, st));
+    const int64_t Tin = Hp * p.P[i], Tout = Hp * p.P[i + 1];
+    // g: d act[i+1] (B, Cout, Hp * P).  Through the SiLU (not after the last layer), in place, zero on pads and gaps.
+    if (i < kDiscLayers - 1) {
+      hipLaunchKernelGGL(disc_silu_bwd_kernel, disc_grid((int64_t)B * l.Cout, Tout), dim3(256), 0, st, g, p.pre[i], Hp, (int)p.P[i + 1],
+                         (int)p.W[i + 1]);
+      DMEL_HIP(hipGetLastError());
+    }
+    // bias and weight gradients: one launch per kernel row, the kw horizontal taps on the grid
+    DMEL_TRY(launch_conv_bgrad(g, grads + d->slot_of(pk + "bias"), l.Cout, B, Tout, st));
     DMEL_HIP(hipMemsetAsync(t.dwfold, 0, (size_t)l.Cout * l.Cin * 3 * l.kw * sizeof(float), st));
     for (int dh = 0; dh < 3; ++dh)
-      for (int dw = 0; dw < l.kw; ++dw)
-        DMEL_TRY(launch_conv_wgrad_strided(g, p.act[i] + (int64_t)(dh - 1) * istr, t.dwfold, l.Cout, l.Cin, l.sw, dw - l.pw, Wout, Win,
-                                           3 * l.kw, dh * l.kw + dw, (int)items, st));
+      DMEL_TRY(launch_conv_wgrad_strided(g, p.act[i] + (int64_t)(dh - 1) * p.P[i], t.dwfold, l.Cout, l.Cin, l.sw, -l.pw, Tout, Tin, 3 * l.kw,
+                                         dh * l.kw, B, st, l.kw));
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)l.Cout), dim3(256), 0, st, t.dwfold, l.v_dev.as<float>(), l.g_dev.as<float>(),
                        grads + d->slot_of(pk + "parametrizations.weight.original0"),
                        grads + d->slot_of(pk + "parametrizations.weight.original1"), (int64_t)l.Cin * 3 * l.kw);
     DMEL_HIP(hipGetLastError());
     if (i == 0 && !dx) break;
-    // backward-data into `other` (items, Cin, Win)
-    float* dst = (g_is_a ? t.gb : t.ga) + istr;
-    DMEL_HIP(zero_buf(dst, l.Cin, Win));
-    int64_t* lenp = i == 0 ? t.len_in : p.len[i - 1];
-    if (i == 0) {
-      hipLaunchKernelGGL(disc_len_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, st, t.len_in, items, Hp, Win);
-      DMEL_HIP(hipGetLastError());
-    }
+    // backward-data into the other buffer (B, Cin, Hp * P[i])
+    float* dst = g_is_a ? t.gb : t.ga;
     const int order[3] = {1, 0, 2};
     for (int k = 0; k < 3; ++k) {
       const int dh = order[k];
       const int nph = l.sw == 1 ? 1 : 2;
       for (int ph = 0; ph < nph; ++ph) {
-        ConvRun r = run_1seg(g - (int64_t)(dh - 1) * ostr, l.Cout, Wout, dst, l.Cin, Win, (int)items);
-        r.out_len = lenp; r.len_div = 1;
+        ConvRun r = run_1seg(g - (int64_t)(dh - 1) * p.P[i + 1], l.Cout, Tout, dst, l.Cin, Tin, B);
         r.accumulate = k > 0;
         if (l.sw == 2) {
-          r.out_tstride = 2; r.phase_base = ph; r.Tcols = (Win - ph + 1) / 2; r.Tout = Win;
+          r.out_tstride = 2; r.phase_base = ph; r.Tcols = Tin / 2; r.Tout = Tin;
         }
-        if (r.Tcols > 0) DMEL_TRY(launch_conv(l.bwd[dh][ph], r, st));
+        DMEL_TRY(launch_conv(l.bwd[dh][ph], r, st));
       }
     }
     g = dst;
     g_is_a = !g_is_a;
   }
-  if (dx) {
-    DMEL_HIP(hipMemcpy2DAsync(dx, (size_t)H * W * sizeof(float), g + W, (size_t)Hp * W * sizeof(float), (size_t)H * W * sizeof(float), B,
-                              hipMemcpyDeviceToDevice, st));
-  }
+  if (dx) DMEL_TRY(disc_extract(g, dx, B, Hp, p.P[0], W, st));      // layer 0 has no SiLU in front: its pads / gaps are simply not read
   return DMEL_OK;
 }
 

@@ -57,9 +57,10 @@ int launch_dwconv_bwd(const float* dh0, const float* x, const float* dw_w, const
 // dw (Cout, Cin, taps) = sum_{b,t} dy[b,co,t] * x[b,ci,t + k*dil - pad], pad = dil*(taps-1)/2; db (Cout) nullable.  Overwrites.
 int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int Cout, int Cin, int taps, int dil, int B, int64_t T,
                       hipStream_t s);
-// one tap of a strided (transposed) conv: dw[(r*Ccols + c)*taps_out + tap_out] += sum_{b,t} rows[b,r,t] * cols[b,c,t*xstride + xoff]
+// `taps` adjacent taps of a strided (transposed) conv:
+//   dw[(r*Ccols + c)*taps_out + tap_out + k] += sum_{b,t} rows[b,r,t] * cols[b,c,t*xstride + xoff + k],  k < taps
 int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, int Crows, int Ccols, int xstride, int xoff, int64_t T,
-                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t s);
+                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t s, int taps = 1);
 int launch_conv_bgrad(const float* dy, float* db, int Cout, int B, int64_t T, hipStream_t s);
 
 }  // namespace dmel
