@@ -18,7 +18,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWgTile = 64;     // workgroup tile: 64 output channels x 64 input channels of one tap
 constexpr int kWgK = 64;        // time samples staged per step
-constexpr int kWgPitch = 66;    // LDS row pitch in floats: bank = 2*row + col -> fragment reads and staging writes conflict-free
+constexpr int kWgPitch = 68;    // LDS row pitch in floats: rows 16-byte aligned for 128-bit fragment reads, 4 banks apart
 
 struct WgArgs {
   const float* dy;
@@ -37,8 +37,8 @@ struct WgArgs {
 // grid (ceil(Cin/64), ceil(Cout/64), taps * slices); 256 threads = 2 x 2 waves of 32 x 32
 template <bool PACK>      // PACK: several short batch items per staged step (per-lane item index); otherwise the item is wave-uniform
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
-  __shared__ float dys[kWgTile * kWgPitch];
-  __shared__ float xs[kWgTile * kWgPitch];
+  __shared__ __attribute__((aligned(16))) float dys[kWgTile * kWgPitch];
+  __shared__ __attribute__((aligned(16))) float xs[kWgTile * kWgPitch];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ci0 = blockIdx.x * kWgTile, co0 = blockIdx.y * kWgTile;
@@ -52,7 +52,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
   const int r31 = lane & 31, h = lane >> 5;
   const int lane_item = PACK ? lane / a.T : 0, lane_t = PACK ? lane - lane_item * a.T : lane;
-  for (int c = c_begin; c < c_end; ++c) {
+  // global loads of step c into registers (clamped addresses, validity kept as bit masks and applied when the values are staged):
+  // they are issued before the MFMA loop of step c - 1, so their latency hides behind it
+  float vd[16], vx[16];
+  unsigned md = 0, mx = 0;
+  auto fetch = [&](int c) {
     int b, t0;
     bool lane_ok = true;
     if (PACK) {                          // c indexes groups of ipc items; every lane has its own item
@@ -66,31 +70,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     }
     const float* dyb = a.dy + (int64_t)b * a.Cout * a.T;
     const float* xb = a.x + (int64_t)b * a.Cin * a.Tx;
-    // stage dy[co0 .. co0+63][t0 .. t0+63] and x[ci0 .. ci0+63][t0+shift ..]: one 256-byte row segment per wave and pass
-    float vd[16], vx[16];
+    const int t = t0 + lane_t, tx = t * a.xstride + a.xoff + shift;
+    const bool tok = lane_ok && t < a.T, txok = tok && tx >= 0 && tx < a.Tx;
+    const int tc = min(t, a.T - 1), txc = min(max(tx, 0), a.Tx - 1);
+    md = 0; mx = 0;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
+    for (int i = 0; i < 16; ++i) {       // one 256-byte row segment per wave and pass
       const int row = wave + 4 * i;
-      const int t = t0 + lane_t, tx = t * a.xstride + a.xoff + shift;
       const int co = co0 + row, ci = ci0 + row;
-      const bool okd = lane_ok && co < a.Cout && t < a.T, okx = lane_ok && ci < a.Cin && t < a.T && tx >= 0 && tx < a.Tx;
-      const float d = dyb[(int64_t)min(co, a.Cout - 1) * a.T + min(t, a.T - 1)];
-      const float v = xb[(int64_t)min(ci, a.Cin - 1) * a.Tx + min(max(tx, 0), a.Tx - 1)];
-      vd[i] = okd ? d : 0.f;
-      vx[i] = okx ? v : 0.f;
+      vd[i] = dyb[(int64_t)min(co, a.Cout - 1) * a.T + tc];
+      vx[i] = xb[(int64_t)min(ci, a.Cin - 1) * a.Tx + txc];
+      md |= (unsigned)(tok && co < a.Cout) << i;
+      mx |= (unsigned)(txok && ci < a.Cin) << i;
     }
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
     __syncthreads();      // the previous step's fragment reads are done
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int row = wave + 4 * i;
-      dys[row * kWgPitch + lane] = vd[i];
-      xs[row * kWgPitch + lane] = vx[i];
+      dys[row * kWgPitch + lane] = (md >> i) & 1 ? vd[i] : 0.f;
+      xs[row * kWgPitch + lane] = (mx >> i) & 1 ? vx[i] : 0.f;
     }
     __syncthreads();
-    const float* ap = dys + (wm * 32 + r31) * kWgPitch + h;
-    const float* bp = xs + (wn * 32 + r31) * kWgPitch + h;
+    if (c + 1 < c_end) fetch(c + 1);
+    // MFMA j of lane half h multiplies staged sample 32 h + j (any pairing of samples works as long as both operands agree),
+    // so every lane reads 32 contiguous floats of its row
+    const float4* ap = reinterpret_cast<const float4*>(dys + (wm * 32 + r31) * kWgPitch + 32 * h);
+    const float4* bp = reinterpret_cast<const float4*>(xs + (wn * 32 + r31) * kWgPitch + 32 * h);
+    float4 av[8], bv[8];
 #pragma unroll
-    for (int j = 0; j < kWgK / 2; ++j) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * j], bp[2 * j], acc, 0, 0, 0);
+    for (int q = 0; q < 8; ++q) { av[q] = ap[q]; bv[q] = bp[q]; }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].x, bv[q].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].y, bv[q].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].z, bv[q].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q].w, bv[q].w, acc, 0, 0, 0);
+    }
   }
   // D[row = co][col = ci]: acc[r] <-> row (r & 3) + 8 * (r >> 2) + 4 * h, col = lane & 31
   const int ci = ci0 + wn * 32 + r31;
