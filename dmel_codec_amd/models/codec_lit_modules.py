@@ -1,8 +1,8 @@
 """VQGAN codec: encode() / decode() on the MI355X.  Drop-in for the inference surface of
 dmel_codec/models/codec_lit_modules.py (reference): same ctor kwargs, attribute names, state-dict prefixes
 (`encoder.*`, `quantizer.*`, `decoder.*`, `quality_projection.*`, `vocoder.*`) and method signatures
-(:462-531).  Lightning is not a dependency: this is a plain nn.Module (the Lightning shell -- optimisers,
-training_step, logging -- is SURVEY.md 8f rank 1, not built yet).
+(:462-531).  Lightning is not a dependency: this is a plain nn.Module that also carries `training_step` / `validation_step`
+(:159-396) and the few trainer hooks they call (`optimizers`, `lr_schedulers`, `manual_backward`, `clip_gradients`, `log`).
 
 Every tensor op of the path is a native HIP launch; torch only owns the memory and the stream."""
 from __future__ import annotations
@@ -242,6 +242,44 @@ class VQGAN(nn.Module):
             optim_g.zero_grad()
             scheduler_g.step()
         return dict(self.logged)
+
+    @torch.no_grad()
+    def validation_step(self, batch, batch_idx, noise: Optional[torch.Tensor] = None):
+        """codec_lit_modules.py:330-396: masked L1 between the re-synthesised and the ground-truth mel with the quality input fixed at 2
+        (the condition is not masked again here, :373-379), logged as "val_loss"; then the vocoder on both mels.  The reference hands
+        figures and audio of the first sample to its logger (:398-460) and returns nothing; the mirror has no logger, so it returns the
+        tensors a caller would log.  `noise` (extension) injects the decoder's Gaussian input."""
+        if self.decoder is None:
+            raise ValueError("Decoder is not loaded")
+        audios, audio_lengths = batch["audios"], batch["audio_lengths"]
+        audios = audios.float()
+        audio_lengths = self._lengths(audio_lengths)
+        gt_transform = self.gt_mel_transform or self.encode_mel_transform
+        encode_mels = self.encode_mel_transform(audios)
+        gt_mels = gt_transform(audios)
+        mel_lengths = audio_lengths.to(gt_mels.device) // gt_transform.hop_length
+        mel_masks = sequence_mask(mel_lengths, gt_mels.shape[2])
+        mel_masks_float_conv = mel_masks[:, None, :].to(torch.float32)
+        gt_mels = gt_mels * mel_masks_float_conv
+        dmel_masks = self.expand_mask(mel_masks_float_conv)
+        batch_size, num_mels, time_size = encode_mels.shape
+        encode_dmels = encode_mels.contiguous().view(batch_size * self.dmel_groups, num_mels // self.dmel_groups, time_size)
+        encode_dmels = encode_dmels * dmel_masks
+        encoded_features = self.encoder(encode_dmels) * dmel_masks
+        vq_recon_features = self.quantizer(encoded_features).z * mel_masks_float_conv
+        two = torch.ones(vq_recon_features.shape[0], 1, device=vq_recon_features.device) * 2
+        vq_recon_features = vq_recon_features + self.quality_projection(two)[:, :, None]
+        if noise is None:
+            noise = torch.randn_like(vq_recon_features)
+        gen_aux_mels = self.decoder(noise * mel_masks_float_conv, condition=vq_recon_features) * mel_masks_float_conv
+        loss_mel = avg_with_mask((gen_aux_mels - gt_mels).abs(), mel_masks_float_conv)
+        self.log("val_loss", loss_mel, batch_size=batch_size)
+        if self.vocoder is None:
+            raise ValueError("Vocoder is not loaded")
+        recon_audios = self.vocoder(gt_mels)
+        gen_aux_audios = self.vocoder(gen_aux_mels)
+        return {"val_loss": loss_mel, "gt_mels": gt_mels, "gen_aux_mels": gen_aux_mels, "recon_audios": recon_audios,
+                "gen_aux_audios": gen_aux_audios}
 
     # ------------------------------------------------------------------------------ encode side
     @torch.no_grad()

@@ -957,6 +957,36 @@ def test_generator_half_of_training_step(dev):
     assert n_checked >= 100
 
 
+def test_validation_step(dev):
+    """VQGAN.validation_step (codec_lit_modules.py:330-396): val_loss, the re-synthesised mel (quality input fixed at 2, condition not
+    re-masked) and both vocoder outputs against the same statements through the oracle; ragged lengths, decoder noise injected."""
+    from dmel_codec_amd.configs import oracle_cfg
+    codec = make_codec(77, n_mels=80, dmel_groups=8, encoder_layers=3, decoder_layers=2)
+    cfg = oracle_cfg(codec)
+    sd, voc = split_sd(codec)
+    gen = torch.Generator().manual_seed(5)
+    L = 4096
+    audio = torch.randn(2, 1, L, generator=gen) * 0.2
+    lens = torch.tensor([[L, 3000]])                     # the collate function's (1, B) shape
+    noise = torch.randn(2, 560, L // 256, generator=gen)
+    h = dict(codec.vocoder.h)
+    loss_ref, gen_ref, gt_ref, recon_ref, aux_ref = ref_cpu.vqgan_validation(sd, cfg, audio, lens, noise, voc, h)
+    loss64, gen64, _, recon64, aux64 = ref_cpu.vqgan_validation(to64(sd), cfg, audio, lens, noise.double(), to64(voc), h)
+    codec = codec.to(dev)
+    batch = {"audios": audio.to(dev), "audio_lengths": lens.to(dev)}
+    out = codec.validation_step(batch, 0, noise=noise.to(dev))
+    assert rel_err(out["gt_mels"], gt_ref) < TOL
+    assert_close_to_truth(out["gen_aux_mels"], gen_ref, gen64, "validation mel")
+    assert abs(out["val_loss"].item() - loss64.item()) < 1e-4 * abs(loss64.item())
+    assert abs(codec.logged["val_loss"] - loss64.item()) < 1e-4 * abs(loss64.item())
+    assert out["recon_audios"].shape == recon_ref.shape and out["gen_aux_audios"].shape == aux_ref.shape
+    assert_close_to_truth(out["recon_audios"], recon_ref, recon64, "vocoder(gt_mels)")
+    assert_close_to_truth(out["gen_aux_audios"], aux_ref, aux64, "vocoder(gen_aux_mels)")
+    codec.vocoder = None
+    with pytest.raises(ValueError, match="Vocoder is not loaded"):
+        codec.validation_step(batch, 0, noise=noise.to(dev))
+
+
 @pytest.mark.parametrize("B,H,W", [(2, 80, 37), (3, 100, 93), (1, 80, 12)])
 def test_discriminator_forward(dev, B, H, W):
     """Native Discriminator forward (every (3, kw) Conv2d as three implicit-GEMM launches over zero-padded image rows; stride-2 layers as
