@@ -12,6 +12,9 @@
 // K across workgroups with fp32 atomics.
 #include "ops.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace dmel {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -121,6 +124,171 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   }
 }
 
+// ---- split-fp32 variant ------------------------------------------------------------------------------------------------
+// The same GEMM on the bf16 matrix core with every fp32 operand written as the exact sum of three bf16 pieces (conv_igemm.hip's
+// arithmetic: six partial products per 32 x 32 x 16 block, dropped terms < 2^-21 relative, fp32 accumulate).  Both operands are
+// time-contiguous, i.e. already K-major: a thread loads eight consecutive samples of one row, splits them and stores three
+// 16-byte units -- exactly one lane's MFMA operand -- into the piece planes of the LDS tile.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kSpRow = 9;         // uint4 units per LDS row: 64 bf16 + 8 pad -> rows 36 banks apart, 128-bit reads conflict-free
+
+__device__ __forceinline__ uint32_t wg_pack_hi16(float lo, float hi) {
+  return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ void wg_split_store(const float (&v)[8], uint4* plane0, int plane_stride, int idx) {
+  uint32_t p1[4], p2[4], p3[4];
+#pragma unroll
+  for (int e = 0; e < 8; e += 2) {
+    const float r0 = v[e] - __uint_as_float(__float_as_uint(v[e]) & 0xffff0000u);
+    const float r1 = v[e + 1] - __uint_as_float(__float_as_uint(v[e + 1]) & 0xffff0000u);
+    const float s0 = r0 - __uint_as_float(__float_as_uint(r0) & 0xffff0000u);
+    const float s1 = r1 - __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+    p1[e >> 1] = wg_pack_hi16(v[e], v[e + 1]);
+    p2[e >> 1] = wg_pack_hi16(r0, r1);
+    p3[e >> 1] = wg_pack_hi16(s0, s1);
+  }
+  plane0[idx] = make_uint4(p1[0], p1[1], p1[2], p1[3]);
+  plane0[plane_stride + idx] = make_uint4(p2[0], p2[1], p2[2], p2[3]);
+  plane0[2 * plane_stride + idx] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
+}
+
+// grid as conv_wgrad_kernel<false>; XS = a.xstride (1 or 2)
+template <int XS>
+__global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
+  constexpr int kPlane = kWgTile * kSpRow;                       // uint4 units per piece plane
+  __shared__ uint4 lds[2 * 3 * kPlane];                          // [operand][piece][row][unit]: 55 KB
+  uint4* const dys = lds;
+  uint4* const xs = lds + 3 * kPlane;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ci0 = blockIdx.x * kWgTile, co0 = blockIdx.y * kWgTile;
+  const int tap = blockIdx.z % a.taps, slice = blockIdx.z / a.taps;
+  const int shift = tap * a.dil - a.pad;
+  floatx16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int total = a.B * a.chunks_per_item;
+  const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int srow = tid >> 3, sg = tid & 7;                       // staging: row within a 32-row pass, group of 8 samples
+
+  // two register sets: the global loads of step c + 2 are issued while step c is multiplied, so a load has two MFMA phases and a
+  // staging phase to arrive
+  float rd[2][2][8], rx[2][2][8];
+  unsigned md[2][2], mx[2][2];
+  auto fetch = [&](auto set, int c) {
+    constexpr int S = decltype(set)::value;
+    const int b = c / a.chunks_per_item;
+    const int t0 = (c - b * a.chunks_per_item) * kWgK;
+    const int t = t0 + 8 * sg;
+    const int txs = t * XS + a.xoff + shift;
+    const float* dyb = a.dy + (int64_t)b * a.Cout * a.T;
+    const float* xb = a.x + (int64_t)b * a.Cin * a.Tx;
+    // wave-uniform choice (a real branch, so the number of loads in flight stays static on either side): a step whose 64 samples
+    // and their displaced x window lie inside the rows uses 128-bit loads, a boundary step clamped scalar loads with validity bits
+    const int xw0 = t0 * XS + a.xoff + shift;
+    const bool interior = t0 + kWgK <= a.T && xw0 >= 0 && xw0 + kWgK * XS <= a.Tx;
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      const int co = co0 + srow + 32 * ps, ci = ci0 + srow + 32 * ps;
+      const float* p = dyb + (int64_t)min(co, a.Cout - 1) * a.T;
+      const float* q = xb + (int64_t)min(ci, a.Cin - 1) * a.Tx;
+      unsigned m0 = 0xffu, m1 = 0xffu;
+      if (interior) {
+        const f4u u0 = *reinterpret_cast<const f4u*>(p + t), u1 = *reinterpret_cast<const f4u*>(p + t + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rd[S][ps][e] = u0[e]; rd[S][ps][4 + e] = u1[e]; }
+        if (XS == 1) {
+          const f4u w0 = *reinterpret_cast<const f4u*>(q + txs), w1 = *reinterpret_cast<const f4u*>(q + txs + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { rx[S][ps][e] = w0[e]; rx[S][ps][4 + e] = w1[e]; }
+        } else {
+#pragma unroll
+          for (int e4 = 0; e4 < 4; ++e4) {
+            const f4u w = *reinterpret_cast<const f4u*>(q + txs + 4 * e4);
+            rx[S][ps][2 * e4] = w[0]; rx[S][ps][2 * e4 + 1] = w[2];
+          }
+        }
+      } else {
+        m0 = 0; m1 = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int tx = txs + e * XS;
+          rd[S][ps][e] = p[min(t + e, a.T - 1)];
+          rx[S][ps][e] = q[min(max(tx, 0), a.Tx - 1)];
+          m0 |= (unsigned)(t + e < a.T) << e;
+          m1 |= (unsigned)(t + e < a.T && tx >= 0 && tx < a.Tx) << e;
+        }
+      }
+      md[S][ps] = co < a.Cout ? m0 : 0u;
+      mx[S][ps] = ci < a.Cin ? m1 : 0u;
+    }
+  };
+  auto step = [&](auto set, int c) {
+    constexpr int S = decltype(set)::value;
+    __syncthreads();      // the previous step's fragment reads are done
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (md[S][ps] >> e) & 1 ? rd[S][ps][e] : 0.f;
+      wg_split_store(v, dys, kPlane, (srow + 32 * ps) * kSpRow + sg);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (mx[S][ps] >> e) & 1 ? rx[S][ps][e] : 0.f;
+      wg_split_store(v, xs, kPlane, (srow + 32 * ps) * kSpRow + sg);
+    }
+    __syncthreads();
+    fetch(set, min(c + 2, c_end - 1));      // unconditional (the tail re-reads the last step): keeps the load count per step static
+    const uint4* ap = dys + (wm * 32 + r31) * kSpRow + hh;
+    const uint4* bp = xs + (wn * 32 + r31) * kSpRow + hh;
+#pragma unroll
+    for (int kk = 0; kk < kWgK / 16; ++kk) {
+      wg_bf16x8 af[3], bf[3];
+#pragma unroll
+      for (int pc = 0; pc < 3; ++pc) {
+        af[pc] = __builtin_bit_cast(wg_bf16x8, ap[pc * kPlane + 2 * kk]);
+        bf[pc] = __builtin_bit_cast(wg_bf16x8, bp[pc * kPlane + 2 * kk]);
+      }
+      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+#pragma unroll
+      for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[u]], bf[PB[u]], acc, 0, 0, 0);
+    }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  if (c_begin >= c_end) return;
+  fetch(S0{}, c_begin);
+  fetch(S1{}, min(c_begin + 1, c_end - 1));
+  int c = c_begin;
+  for (; c + 1 < c_end; c += 2) {     // pairs, so that neither step sits behind a condition
+    step(S0{}, c);
+    step(S1{}, c + 1);
+  }
+  if (c < c_end) step(S0{}, c);
+  const int ci = ci0 + wn * 32 + r31;
+  if (ci < a.Cin) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+      if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps_out + a.tap_out + tap, acc[r]);
+    }
+  }
+}
+
+// DMEL_WGRAD_FP32_MFMA=1 keeps every weight gradient on the native fp32 MFMA kernel (A/B switch)
+static bool wgrad_native_only() {
+  static const bool v = [] { const char* e = getenv("DMEL_WGRAD_FP32_MFMA"); return e && e[0] == '1'; }();
+  return v;
+}
+static void launch_wgrad_any(const WgArgs& a, dim3 grid, hipStream_t st) {
+  if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
+  // short rows are mostly boundary steps (scalar loads in the split kernel): they stay on the fp32-MFMA kernel
+  else if (wgrad_native_only() || a.xstride > 2 || a.T < 256) hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
+  else if (a.xstride == 1) hipLaunchKernelGGL(conv_wgrad_split_kernel<1>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(conv_wgrad_split_kernel<2>, grid, dim3(256), 0, st, a);
+}
+
 // db[co] = sum over (b, t): one workgroup per output channel
 __global__ __launch_bounds__(256) void conv_bgrad_kernel(const float* __restrict__ dy, float* __restrict__ db, int Cout, int B, int T) {
   __shared__ float part[4];
@@ -158,8 +326,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   dim3 grid((unsigned)((Cin + kWgTile - 1) / kWgTile), (unsigned)((Cout + kWgTile - 1) / kWgTile), (unsigned)(taps * slices));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Cout * Cin * taps, 0.0);
-    if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
+    launch_wgrad_any(a, grid, st);
   }
   DMEL_HIP(hipGetLastError());
   if (db) {
@@ -191,8 +358,7 @@ int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, i
   dim3 grid((unsigned)((Ccols + kWgTile - 1) / kWgTile), (unsigned)((Crows + kWgTile - 1) / kWgTile), (unsigned)(slices * taps));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols * taps, 0.0);
-    if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
+    launch_wgrad_any(a, grid, st);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
