@@ -153,52 +153,67 @@ __device__ __forceinline__ void wg_split_store(const float (&v)[8], uint4* plane
   plane0[2 * plane_stride + idx] = make_uint4(p3[0], p3[1], p3[2], p3[3]);
 }
 
-// grid as conv_wgrad_kernel<false>; XS = a.xstride (1 or 2)
-template <int XS>
+// XS = a.xstride (1 or 2); workgroup tile (64 MT) x (64 NT) output x input channels, 2 x 2 waves of (32 MT) x (32 NT); KS samples per
+// staged step.  <1, 1, 64>: the fp32 kernel's tile (default).  <2, 2, 32>: 128 x 128, twice the flops per byte moved from L2 (opt-in).
+// grid (ceil(Cin / (64 NT)), ceil(Cout / (64 MT)), taps * slices); a.chunks_per_item counts KS-sample steps.
+template <int XS, int MT, int NT, int KS>
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
-  constexpr int kPlane = kWgTile * kSpRow;                       // uint4 units per piece plane
-  __shared__ uint4 lds[2 * 3 * kPlane];                          // [operand][piece][row][unit]: 55 KB
+  constexpr int UR = KS / 8 + 1;                                 // uint4 units per LDS row incl. one pad unit: conflict-free 128-bit reads
+  constexpr int RM = 64 * MT, RN = 64 * NT;                      // staged rows of dy / x
+  constexpr int kPlaneD = RM * UR, kPlaneX = RN * UR;            // uint4 units per piece plane
+  constexpr int G = KS / 8, RP = 256 / G;                        // 8-sample groups per row, rows per staging pass
+  constexpr int PD = RM / RP, PX = RN / RP;                      // staging passes
+  static_assert(RM % RP == 0 && RN % RP == 0 && 3 * (kPlaneD + kPlaneX) * 16 <= 65536, "tile does not fit");
+  __shared__ uint4 lds[3 * (kPlaneD + kPlaneX)];                 // [operand][piece][row][unit]
   uint4* const dys = lds;
-  uint4* const xs = lds + 3 * kPlane;
+  uint4* const xs = lds + 3 * kPlaneD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int ci0 = blockIdx.x * kWgTile, co0 = blockIdx.y * kWgTile;
+  const int ci0 = blockIdx.x * RN, co0 = blockIdx.y * RM;
   const int tap = blockIdx.z % a.taps, slice = blockIdx.z / a.taps;
   const int shift = tap * a.dil - a.pad;
-  floatx16 acc;
+  floatx16 acc[MT][NT];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
   const int total = a.B * a.chunks_per_item;
   const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
   const int r31 = lane & 31, hh = lane >> 5;
-  const int srow = tid >> 3, sg = tid & 7;                       // staging: row within a 32-row pass, group of 8 samples
+  const int srow = tid / G, sg = tid % G;                        // staging: row within a pass, group of 8 samples
 
   // two register sets: the global loads of step c + 2 are issued while step c is multiplied, so a load has two MFMA phases and a
   // staging phase to arrive
-  float rd[2][2][8], rx[2][2][8];
-  unsigned md[2][2], mx[2][2];
+  float rd[2][PD][8], rx[2][PX][8];
+  unsigned md[2][PD], mx[2][PX];
   auto fetch = [&](auto set, int c) {
     constexpr int S = decltype(set)::value;
     const int b = c / a.chunks_per_item;
-    const int t0 = (c - b * a.chunks_per_item) * kWgK;
+    const int t0 = (c - b * a.chunks_per_item) * KS;
     const int t = t0 + 8 * sg;
     const int txs = t * XS + a.xoff + shift;
     const float* dyb = a.dy + (int64_t)b * a.Cout * a.T;
     const float* xb = a.x + (int64_t)b * a.Cin * a.Tx;
-    // wave-uniform choice (a real branch, so the number of loads in flight stays static on either side): a step whose 64 samples
+    // wave-uniform choice (a real branch, so the number of loads in flight stays static on either side): a step whose samples
     // and their displaced x window lie inside the rows uses 128-bit loads, a boundary step clamped scalar loads with validity bits
     const int xw0 = t0 * XS + a.xoff + shift;
-    const bool interior = t0 + kWgK <= a.T && xw0 >= 0 && xw0 + kWgK * XS <= a.Tx;
+    const bool interior = t0 + KS <= a.T && xw0 >= 0 && xw0 + KS * XS <= a.Tx;
+    if (interior) {
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int co = co0 + srow + 32 * ps, ci = ci0 + srow + 32 * ps;
-      const float* p = dyb + (int64_t)min(co, a.Cout - 1) * a.T;
-      const float* q = xb + (int64_t)min(ci, a.Cin - 1) * a.Tx;
-      unsigned m0 = 0xffu, m1 = 0xffu;
-      if (interior) {
+      for (int ps = 0; ps < PD; ++ps) {
+        const int co = co0 + srow + RP * ps;
+        const float* p = dyb + (int64_t)min(co, a.Cout - 1) * a.T;
         const f4u u0 = *reinterpret_cast<const f4u*>(p + t), u1 = *reinterpret_cast<const f4u*>(p + t + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { rd[S][ps][e] = u0[e]; rd[S][ps][4 + e] = u1[e]; }
+        md[S][ps] = co < a.Cout ? 0xffu : 0u;
+      }
+#pragma unroll
+      for (int ps = 0; ps < PX; ++ps) {
+        const int ci = ci0 + srow + RP * ps;
+        const float* q = xb + (int64_t)min(ci, a.Cin - 1) * a.Tx;
         if (XS == 1) {
           const f4u w0 = *reinterpret_cast<const f4u*>(q + txs), w1 = *reinterpret_cast<const f4u*>(q + txs + 4);
 #pragma unroll
@@ -210,49 +225,75 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
             rx[S][ps][2 * e4] = w[0]; rx[S][ps][2 * e4 + 1] = w[2];
           }
         }
-      } else {
-        m0 = 0; m1 = 0;
+        mx[S][ps] = ci < a.Cin ? 0xffu : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < PD; ++ps) {
+        const int co = co0 + srow + RP * ps;
+        const float* p = dyb + (int64_t)min(co, a.Cout - 1) * a.T;
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          rd[S][ps][e] = p[min(t + e, a.T - 1)];
+          m |= (unsigned)(t + e < a.T) << e;
+        }
+        md[S][ps] = co < a.Cout ? m : 0u;
+      }
+#pragma unroll
+      for (int ps = 0; ps < PX; ++ps) {
+        const int ci = ci0 + srow + RP * ps;
+        const float* q = xb + (int64_t)min(ci, a.Cin - 1) * a.Tx;
+        unsigned m = 0;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int tx = txs + e * XS;
-          rd[S][ps][e] = p[min(t + e, a.T - 1)];
           rx[S][ps][e] = q[min(max(tx, 0), a.Tx - 1)];
-          m0 |= (unsigned)(t + e < a.T) << e;
-          m1 |= (unsigned)(t + e < a.T && tx >= 0 && tx < a.Tx) << e;
+          m |= (unsigned)(t + e < a.T && tx >= 0 && tx < a.Tx) << e;
         }
+        mx[S][ps] = ci < a.Cin ? m : 0u;
       }
-      md[S][ps] = co < a.Cout ? m0 : 0u;
-      mx[S][ps] = ci < a.Cin ? m1 : 0u;
     }
   };
   auto step = [&](auto set, int c) {
     constexpr int S = decltype(set)::value;
     __syncthreads();      // the previous step's fragment reads are done
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
+    for (int ps = 0; ps < PD; ++ps) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (md[S][ps] >> e) & 1 ? rd[S][ps][e] : 0.f;
-      wg_split_store(v, dys, kPlane, (srow + 32 * ps) * kSpRow + sg);
+      wg_split_store(v, dys, kPlaneD, (srow + RP * ps) * UR + sg);
+    }
+#pragma unroll
+    for (int ps = 0; ps < PX; ++ps) {
+      float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (mx[S][ps] >> e) & 1 ? rx[S][ps][e] : 0.f;
-      wg_split_store(v, xs, kPlane, (srow + 32 * ps) * kSpRow + sg);
+      wg_split_store(v, xs, kPlaneX, (srow + RP * ps) * UR + sg);
     }
     __syncthreads();
     fetch(set, min(c + 2, c_end - 1));      // unconditional (the tail re-reads the last step): keeps the load count per step static
-    const uint4* ap = dys + (wm * 32 + r31) * kSpRow + hh;
-    const uint4* bp = xs + (wn * 32 + r31) * kSpRow + hh;
+    const uint4* ap = dys + (wm * 32 * MT + r31) * UR + hh;
+    const uint4* bp = xs + (wn * 32 * NT + r31) * UR + hh;
 #pragma unroll
-    for (int kk = 0; kk < kWgK / 16; ++kk) {
-      wg_bf16x8 af[3], bf[3];
+    for (int kk = 0; kk < KS / 16; ++kk) {
+      wg_bf16x8 af[MT][3], bf[NT][3];
 #pragma unroll
       for (int pc = 0; pc < 3; ++pc) {
-        af[pc] = __builtin_bit_cast(wg_bf16x8, ap[pc * kPlane + 2 * kk]);
-        bf[pc] = __builtin_bit_cast(wg_bf16x8, bp[pc * kPlane + 2 * kk]);
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) af[mi][pc] = __builtin_bit_cast(wg_bf16x8, ap[pc * kPlaneD + mi * 32 * UR + 2 * kk]);
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) bf[ni][pc] = __builtin_bit_cast(wg_bf16x8, bp[pc * kPlaneX + ni * 32 * UR + 2 * kk]);
       }
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
 #pragma unroll
-      for (int u = 0; u < 6; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[u]], bf[PB[u]], acc, 0, 0, 0);
+      for (int u = 0; u < 6; ++u)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < NT; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][PA[u]], bf[ni][PB[u]], acc[mi][ni], 0, 0, 0);
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -266,14 +307,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
     step(S1{}, c + 1);
   }
   if (c < c_end) step(S0{}, c);
-  const int ci = ci0 + wn * 32 + r31;
-  if (ci < a.Cin) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-      if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps_out + a.tap_out + tap, acc[r]);
+  for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+      const int ci = ci0 + (wn * NT + ni) * 32 + r31;
+      if (ci < a.Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int co = co0 + (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps_out + a.tap_out + tap, acc[mi][ni][r]);
+        }
+      }
     }
-  }
 }
 
 // DMEL_WGRAD_FP32_MFMA=1 keeps every weight gradient on the native fp32 MFMA kernel (A/B switch)
@@ -281,12 +327,37 @@ static bool wgrad_native_only() {
   static const bool v = [] { const char* e = getenv("DMEL_WGRAD_FP32_MFMA"); return e && e[0] == '1'; }();
   return v;
 }
-static void launch_wgrad_any(const WgArgs& a, dim3 grid, hipStream_t st) {
-  if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
+// DMEL_WGRAD_TILE128=1 moves the split kernel to its 128 x 128 x 32 instantiation where both channel counts allow (A/B switch).
+// Measured slower than 64 x 64 x 64 on every shape (42-81 vs 67-92 TF/s): 256 VGPRs and 60 KB of LDS leave one or two workgroups
+// per CU, and a 32-sample step has two barriers per 48 MFMAs -- the kernel is bound by latency between barriers, not by L2 bytes.
+static bool wgrad_big_tile() {
+  static const bool v = [] { const char* e = getenv("DMEL_WGRAD_TILE128"); return e && e[0] == '1'; }();
+  return v;
+}
+// picks the kernel, then the K slicing for its tile and step (a: everything but chunks_per_item / ipc / slices / chunks_per_slice)
+static void launch_wgrad_any(WgArgs a, hipStream_t st) {
+  a.ipc = a.T <= 32 ? kWgK / a.T : 1;
   // short rows are mostly boundary steps (scalar loads in the split kernel): they stay on the fp32-MFMA kernel
-  else if (wgrad_native_only() || a.xstride > 2 || a.T < 256) hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
-  else if (a.xstride == 1) hipLaunchKernelGGL(conv_wgrad_split_kernel<1>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(conv_wgrad_split_kernel<2>, grid, dim3(256), 0, st, a);
+  const bool split = a.ipc == 1 && !wgrad_native_only() && a.xstride <= 2 && a.T >= 256;
+  const bool big = split && a.Cout >= 128 && a.Cin >= 128 && wgrad_big_tile();
+  const int tile = big ? 128 : kWgTile, ks = big ? 32 : kWgK;
+  a.chunks_per_item = (a.T + ks - 1) / ks;
+  const int tm = (a.Cout + tile - 1) / tile, tn = (a.Cin + tile - 1) / tile;
+  const int tiles = tm * tn * a.taps;
+  const int total = a.ipc > 1 ? (a.B + a.ipc - 1) / a.ipc : a.B * a.chunks_per_item;
+  // enough K slices to fill the chip (~8 workgroups of the small tile / ~4 of the large one per CU), each at least 8 staged steps long
+  const int want = big ? 1024 : 2048;
+  int slices = std::max(1, std::min((want + tiles - 1) / tiles, (total + 7) / 8));
+  slices = std::min(slices, 65535 / a.taps);
+  a.slices = slices;
+  a.chunks_per_slice = (total + slices - 1) / slices;
+  const dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)(a.taps * slices));
+  if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
+  else if (!split) hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
+  else if (big && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 2, 2, 32>), grid, dim3(256), 0, st, a);
+  else if (big) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 2, 2, 32>), grid, dim3(256), 0, st, a);
+  else if (a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1, 1, 64>), grid, dim3(256), 0, st, a);
 }
 
 // db[co] = sum over (b, t): one workgroup per output channel
@@ -313,20 +384,10 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   a.dy = dy; a.x = x; a.dw = dw;
   a.Cout = Cout; a.Cin = Cin; a.taps = taps; a.dil = dil; a.pad = dil * (taps - 1) / 2; a.B = B; a.T = (int)T;
   a.xstride = 1; a.xoff = 0; a.Tx = (int)T; a.taps_out = taps; a.tap_out = 0;
-  a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
-  a.ipc = T <= 32 ? (int)(kWgK / T) : 1;
-  const int tiles = ((Cin + kWgTile - 1) / kWgTile) * ((Cout + kWgTile - 1) / kWgTile) * taps;
-  const int total = a.ipc > 1 ? (B + a.ipc - 1) / a.ipc : B * a.chunks_per_item;
-  // enough K slices to fill the chip (~8 workgroups per CU), each at least 8 staged steps long
-  int slices = std::max(1, std::min((2048 + tiles - 1) / tiles, (total + 7) / 8));
-  slices = std::min(slices, 65535 / std::max(1, taps));
-  a.slices = slices;
-  a.chunks_per_slice = (total + slices - 1) / slices;
   DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * taps * sizeof(float), st));
-  dim3 grid((unsigned)((Cin + kWgTile - 1) / kWgTile), (unsigned)((Cout + kWgTile - 1) / kWgTile), (unsigned)(taps * slices));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Cout * Cin * taps, 0.0);
-    launch_wgrad_any(a, grid, st);
+    launch_wgrad_any(a, st);
   }
   DMEL_HIP(hipGetLastError());
   if (db) {
@@ -347,18 +408,9 @@ int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, i
   a.dy = rows; a.x = cols; a.dw = dw;
   a.Cout = Crows; a.Cin = Ccols; a.taps = taps; a.dil = 1; a.pad = 0; a.B = B; a.T = (int)T;
   a.xstride = xstride; a.xoff = xoff; a.Tx = (int)Tx; a.taps_out = taps_out; a.tap_out = tap_out;
-  a.chunks_per_item = (int)((T + kWgK - 1) / kWgK);
-  a.ipc = T <= 32 ? (int)(kWgK / T) : 1;
-  const int tiles = ((Ccols + kWgTile - 1) / kWgTile) * ((Crows + kWgTile - 1) / kWgTile);
-  const int total = a.ipc > 1 ? (B + a.ipc - 1) / a.ipc : B * a.chunks_per_item;
-  int slices = std::max(1, std::min((2048 + tiles * taps - 1) / (tiles * taps), (total + 7) / 8));
-  slices = std::min(slices, 65535 / taps);
-  a.slices = slices;
-  a.chunks_per_slice = (total + slices - 1) / slices;
-  dim3 grid((unsigned)((Ccols + kWgTile - 1) / kWgTile), (unsigned)((Crows + kWgTile - 1) / kWgTile), (unsigned)(slices * taps));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols * taps, 0.0);
-    launch_wgrad_any(a, grid, st);
+    launch_wgrad_any(a, st);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
