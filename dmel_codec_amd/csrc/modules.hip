@@ -1325,10 +1325,9 @@ extern "C" int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, 
 // =====================================================================================================
 // Six weight-normed Conv2d over the mel image (B, 1, H = n_mels, W = frames), kernels (3, kw), stride (1, sw), SiLU in between.
 // A (3, kw) Conv2d is three 1-D convolutions over W, one per kernel row dh, summed: y[:, h] += conv1d_dh(x[:, h + dh - 1]).
-// Activations are kept as (B, H + 2, C, W): one ITEM per image row with a zero pad row above and below every image, so that row
-// h + dh - 1 of the input is simply the neighbouring item (a pointer offset) and the implicit-GEMM conv kernel runs unchanged with
-// batch = B * (H + 2) items; the output rows of the pad items are forced to zero by the kernel's per-item length mask.  A stride-2
-// convolution over W is the sum of its two polyphase branches (even taps on x[2w'], odd taps on x[2w' + 1]): two K segments.
+// Activations are kept in a flattened, zero-padded image layout (see DPlan below) in which row h + dh - 1 of the input is the same
+// buffer displaced by one row pitch, so the implicit-GEMM conv kernel runs unchanged over B long items.  A stride-2 convolution
+// over W is the sum of its two polyphase branches (even taps on x[2w'], odd taps on x[2w' + 1]): two K segments.
 namespace {
 struct DLayer {
   int Cin, Cout, kw, sw, pw;

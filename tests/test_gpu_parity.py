@@ -989,7 +989,7 @@ def test_validation_step(dev):
 
 @pytest.mark.parametrize("B,H,W", [(2, 80, 37), (3, 100, 93), (1, 80, 12)])
 def test_discriminator_forward(dev, B, H, W):
-    """Native Discriminator forward (every (3, kw) Conv2d as three implicit-GEMM launches over zero-padded image rows; stride-2 layers as
+    """Native Discriminator forward (every (3, kw) Conv2d as three implicit-GEMM launches over displaced views of the flattened zero-padded image; stride-2 layers as
     two polyphase K segments) against the oracle, whose restatement is pinned to the reference class by a CPU fixture."""
     from dmel_codec_amd.models.modules.discriminator import Discriminator
     sd = ref_cpu.seeded_discriminator_sd(4242 + W)
