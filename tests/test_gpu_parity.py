@@ -987,10 +987,10 @@ def test_validation_step(dev):
         codec.validation_step(batch, 0, noise=noise.to(dev))
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 80, 37), (3, 100, 93), (1, 80, 12)])
+@pytest.mark.parametrize("B,H,W", [(2, 80, 37), (3, 100, 93), (1, 80, 12), (1, 80, 60), (1, 16, 200), (2, 3, 5)])
 def test_discriminator_forward(dev, B, H, W):
-    """Native Discriminator forward (every (3, kw) Conv2d as three implicit-GEMM launches over displaced views of the flattened zero-padded image; stride-2 layers as
-    two polyphase K segments) against the oracle, whose restatement is pinned to the reference class by a CPU fixture."""
+    """Native Discriminator forward (every (3, kw) Conv2d as three implicit-GEMM launches over displaced views of the flattened,
+    zero-padded image; stride-2 layers as two polyphase K segments) against the oracle, whose restatement is pinned to the reference class by a CPU fixture."""
     from dmel_codec_amd.models.modules.discriminator import Discriminator
     sd = ref_cpu.seeded_discriminator_sd(4242 + W)
     d = Discriminator()
@@ -1006,9 +1006,9 @@ def test_discriminator_forward(dev, B, H, W):
     assert_close_to_truth(y, ref, ref64, "discriminator logits")
 
 
-@pytest.mark.parametrize("B,H,W", [(2, 80, 37), (1, 80, 93)])
+@pytest.mark.parametrize("B,H,W", [(2, 80, 37), (1, 80, 93), (1, 16, 60), (1, 8, 300)])
 def test_discriminator_backward(dev, B, H, W):
-    """Native discriminator backward (transposed convs per kernel row / output phase, single-tap weight-gradient GEMMs, chain through
+    """Native discriminator backward (transposed convs per kernel row / output phase, multi-tap strided weight-gradient GEMMs, chain through
     weight norm) against autograd through the oracle in float64 (itself pinned to the reference class's autograd by a CPU fixture):
     d input, and bias / weight-norm g / v gradients of all six layers."""
     from dmel_codec_amd.models.modules.discriminator import Discriminator
