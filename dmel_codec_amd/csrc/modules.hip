@@ -1484,7 +1484,7 @@ struct DPlan {
   size_t bytes;
 };
 int64_t disc_pitch0(const dmel_discriminator* d, int64_t W) {
-  for (int64_t P0 = (W + 4 + 63) / 64 * 64;; P0 += 64) {
+  for (int64_t P0 = (W + 4 + 15) / 16 * 16;; P0 += 16) {      // multiples of 16: the pitch stays even after three halvings
     int64_t w = W, P = P0;
     bool ok = true;
     for (int i = 0; i < kDiscLayers && ok; ++i) {
