@@ -87,7 +87,7 @@ def cpu_baseline(codec, workload: str, seconds_per_clip: float, budget_s: float)
     all_cores = torch.get_num_threads()
     one()                                    # warm-up (thread pools, oneDNN primitives)
     calib = {}
-    for th in sorted({1, 8, 32, all_cores}):
+    for th in sorted({8, 32, all_cores}):
         if th > all_cores:
             continue
         torch.set_num_threads(th)
@@ -113,6 +113,20 @@ def cpu_baseline(codec, workload: str, seconds_per_clip: float, budget_s: float)
             "one_pass_audio_sec_per_sec_by_threads": {str(k): round(n * seconds_per_clip / v, 3) for k, v in calib.items()}}
 
 
+def committed_traffic():
+    """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc, separate runs, corrected as the MI355X guide
+    prescribes).  bench.py cannot read hardware counters itself: the figure is the one committed with the profile it came from
+    (profiles/pmc_traffic.json: {"bytes_per_launch": ..., "source": ...}); null when no such file travels with the repo."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return {"bytes_per_launch": d["bytes_per_launch"], "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"),
+                "source": d.get("source")}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def max_over_ranks(dist, elapsed: float, device) -> float:
     """Timing contract: the step time of the job is the slowest rank's."""
     if dist is None:
@@ -127,6 +141,48 @@ def job_rate(world: int, batch: int, seconds: float, steps: int, elapsed: float)
     return world * batch * seconds * steps / elapsed
 
 
+def spawn_ranks(n: int, argv, script: str | None = None, have: int | None = None) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: become the launcher.  The N ranks are CHILD processes started before
+    this process has touched the GPU (device_count() does not initialise HIP on this image; nothing here execs a process that has),
+    one per device, wired with the same RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables torch.distributed.run sets.  Rank 0's
+    stdout (the one JSON line) is forwarded; the exit code is non-zero if any rank fails."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count() if have is None else have
+    if have < n:
+        print(f"bench.py --gpus {n} needs {n} devices on this node, found {have}", file=sys.stderr)
+        return 2
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__), *argv], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for pr in list(pending):
+                code = pr.poll()
+                if code is None:
+                    continue
+                pending.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for other in pending:                  # a failed rank leaves the others in a collective: stop them
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +192,8 @@ def main() -> None:
     ap.add_argument("--seconds", type=float, default=1.0, help="clip length")
     ap.add_argument("--workload", default="cfg2", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work for the baseline (0 = skip)")
+    ap.add_argument("--median-steps", type=int, default=100,
+                    help="extra steps timed one by one with events for the median / p10 / p90 of the step time (0 = skip)")
     ap.add_argument("--streams", type=int, default=3, choices=(1, 3),
                     help="streams BigVGAN's AMP blocks overlap on in the timed region (1 = serialised, for rocprofv3 runs)")
     ap.add_argument("--decode-precision", default="fp32", choices=("fp32", "bf16"),
@@ -143,13 +201,12 @@ def main() -> None:
                          "decode-side convolutions (never the default: it is outside the 1e-4 bar)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))     # plain `python bench.py --gpus N`: start the N ranks ourselves
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed launch (python -m torch.distributed.run "
-                             f"--nproc-per-node {args.gpus} bench.py ...)")
         raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
@@ -163,7 +220,12 @@ def main() -> None:
         dist = dist_mod
 
     from dmel_codec_amd import _lib
-    codec = build(args.workload).to(dev)
+    codec = build(args.workload)
+    cpu_base = None
+    if world == 1 and rank == 0 and args.cpu_budget > 0:
+        # the host-core baseline runs first, on the freshly built (CPU-resident) weights, so the GPU legs close the run
+        cpu_base = cpu_baseline(codec, args.workload, args.seconds, args.cpu_budget)
+    codec = codec.to(dev)
     sr = WORKLOADS[args.workload]["sample_rate"]
     L = int(sr * args.seconds)
     audio = synth_audio(args.batch, L, 1234 + rank).to(dev)      # every rank its own utterances
@@ -191,6 +253,18 @@ def main() -> None:
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(dist, elapsed, dev)
+
+    # Distribution of the step time: `median_steps` further steps, each bracketed by its own pair of events on the launch stream
+    # (the vocoder's side streams fork from and join back into it, so the pair sees the whole step).
+    per_step_ms = []
+    if args.median_steps > 0:
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.median_steps)]
+        for a, b in evs:
+            a.record()
+            step()
+            b.record()
+        sync_all()
+        per_step_ms = sorted(a.elapsed_time(b) for a, b in evs)
 
     # Per-kernel roofline pass.  In the timed region above BigVGAN's three AMP blocks run on three streams, so kernels
     # overlap and a kernel's own hipEvent interval no longer measures that kernel alone.  The same K steps are therefore
@@ -235,6 +309,9 @@ def main() -> None:
             "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "ms_per_step_events": ({"n": len(per_step_ms), "median": round(per_step_ms[len(per_step_ms) // 2], 3),
+                                    "p10": round(per_step_ms[len(per_step_ms) // 10], 3),
+                                    "p90": round(per_step_ms[(9 * len(per_step_ms)) // 10], 3)} if per_step_ms else None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 operands, f32 accumulate in the decode convolutions (opt-in mode); f32 elsewhere" if bf16 else "f32",
             "data": "synthetic",
@@ -245,7 +322,7 @@ def main() -> None:
                        "vocoder_streams": args.streams},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": None,
+                         "frac": round(ach / peak, 4), "traffic": committed_traffic(),
                          "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launches_per_step": conv["launches"] // max(1, args.steps),
                          "avg_launch_us": round(1e3 * conv["ms"] / max(1, conv["launches"]), 2),
@@ -258,8 +335,8 @@ def main() -> None:
             "aa_snake_hbm": {"achieved_GBs": round(snake["bytes"] / (snake["ms"] * 1e-3) / 1e9, 1) if snake["ms"] > 0 else 0.0,
                              "peak_GBs": PEAK_HBM_GBS},
         }
-        if world == 1 and args.cpu_budget > 0:
-            out["cpu_baseline"] = cpu_baseline(codec.cpu(), args.workload, args.seconds, args.cpu_budget)
+        if cpu_base is not None:
+            out["cpu_baseline"] = cpu_base
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

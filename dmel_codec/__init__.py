@@ -12,6 +12,9 @@ _ALIASES = {
     "dmel_codec.utils.spectrogram": "dmel_codec_amd.utils.spectrogram",
     "dmel_codec.utils.utils": "dmel_codec_amd.utils.utils",
     "dmel_codec.utils.schedule": "dmel_codec_amd.utils.schedule",
+    "dmel_codec.dataset": "dmel_codec_amd.dataset",
+    "dmel_codec.dataset.lhotse_tts_dataset": "dmel_codec_amd.dataset.lhotse_tts_dataset",
+    "dmel_codec.dataset.synthetic": "dmel_codec_amd.dataset.synthetic",
     "dmel_codec.models": "dmel_codec_amd.models",
     "dmel_codec.models.codec_lit_modules": "dmel_codec_amd.models.codec_lit_modules",
     "dmel_codec.models.lit_modules": "dmel_codec_amd.models.codec_lit_modules",   # stale path used by dMel_used.yaml:40

@@ -19,6 +19,7 @@ i64p = C.POINTER(C.c_int64)
 i32p = C.POINTER(C.c_int32)
 f32p = C.POINTER(C.c_float)
 vp = C.c_void_p
+GRAD_READY_FN = C.CFUNCTYPE(None, vp, C.c_int64, C.c_int64)     # dmel_grad_ready_fn (include/dmel_hip.h)
 
 
 class BigVGANConfig(C.Structure):
@@ -86,6 +87,7 @@ PROTOTYPES = {
     "dmel_wavenet_grad_slot": (C.c_int, [vp, C.c_char_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "dmel_wavenet_forward_train": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_wavenet_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
+    "dmel_wavenet_backward_hooked": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp, GRAD_READY_FN, vp]),
     "dmel_wavenet_set_tensor": (C.c_int, [vp, C.c_char_p, vp, i64p, C.c_int]),
     "dmel_wavenet_finalize": (C.c_int, [vp]),
     "dmel_wavenet_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),

@@ -30,6 +30,15 @@ _Loader.add_implicit_resolver(
                r"|[-+]?\.(?:inf|Inf|INF)|\.(?:nan|NaN|NAN))$"),
     list("-+0123456789."))
 _ALIASES = {"dmel_codec.models.lit_modules": "dmel_codec_amd.models.codec_lit_modules"}
+# Lightning's trainer / callbacks / logger named by the reference's configs (dMel_example.yaml:4-14,127-157): Lightning is not a
+# dependency; the slice train_codec.py uses lives in dmel_codec_amd.trainer
+_TARGET_ALIASES = {
+    "lightning.pytorch.Trainer": "dmel_codec_amd.trainer.Trainer",
+    "lightning.pytorch.callbacks.ModelCheckpoint": "dmel_codec_amd.trainer.ModelCheckpoint",
+    "lightning.pytorch.callbacks.RichProgressBar": "dmel_codec_amd.trainer.RichProgressBar",
+    "lightning.pytorch.callbacks.ModelSummary": "dmel_codec_amd.trainer.ModelSummary",
+    "lightning.pytorch.loggers.TensorBoardLogger": "dmel_codec_amd.trainer.JsonlLogger",
+}
 
 
 def merge(base: dict, over: Mapping) -> dict:
@@ -105,6 +114,7 @@ def _flatten(node, prefix=""):
 
 
 def locate(target: str):
+    target = _TARGET_ALIASES.get(target, target)
     module, _, name = target.rpartition(".")
     module = _ALIASES.get(module, module)
     if module == "dmel_codec" or module.startswith("dmel_codec."):

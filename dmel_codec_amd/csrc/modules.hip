@@ -525,6 +525,12 @@ extern "C" int dmel_wavenet_forward_train(const dmel_wavenet* m, const float* x,
 extern "C" int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, const float* condition, const float* dy, float* dx,
                                      float* dcondition, float* grads, int N, int64_t T, void* workspace, size_t workspace_bytes,
                                      void* stream) {
+  return dmel_wavenet_backward_hooked(m, x, condition, dy, dx, dcondition, grads, N, T, workspace, workspace_bytes, stream, nullptr, nullptr);
+}
+
+extern "C" int dmel_wavenet_backward_hooked(const dmel_wavenet* m, const float* x, const float* condition, const float* dy, float* dx,
+                                            float* dcondition, float* grads, int N, int64_t T, void* workspace,
+                                            size_t workspace_bytes, void* stream, dmel_grad_ready_fn on_ready, void* user) {
   DMEL_CHECK_ARG(m && x && dy && grads && workspace, "wavenet_backward: NULL argument");
   if (!m->ready || !m->train_ready) { set_error("wavenet_backward: enable_training + finalize first"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG((m->Ccond != 0) == (condition != nullptr), "wavenet_backward: condition tensor does not match the configuration");
@@ -538,6 +544,19 @@ extern "C" int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, cons
     for (const auto& s : m->slots)
       if (s.key == key) return grads + s.offset;
     return nullptr;
+  };
+  // contiguous region of the flat gradient buffer that belongs to the slots whose key starts with `prefix` (slots are laid out
+  // input_projection | residual_layers.0 | ... | residual_layers.L-1 | skip_projection | output_projection)
+  auto ready = [&](const std::string& prefix, const std::string& prefix2 = std::string()) {
+    if (!on_ready) return;
+    int64_t lo = -1, hi = -1;
+    for (const auto& s : m->slots) {
+      const bool hit = s.key.compare(0, prefix.size(), prefix) == 0 || (!prefix2.empty() && s.key.compare(0, prefix2.size(), prefix2) == 0);
+      if (!hit) continue;
+      if (lo < 0) lo = s.offset;
+      hi = s.offset + s.numel;
+    }
+    if (lo >= 0) on_ready(user, lo, hi - lo);
   };
   // ---- tail: y = out_proj(silu(P)), P = skip_proj(XS), XS = SK / sqrt(L) ----
   const float* dP = dy;
@@ -556,6 +575,7 @@ extern "C" int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, cons
     DMEL_TRY(launch_conv(m->skip_dx, r, st));
     DMEL_TRY(launch_scale(p.DZ, p.GS, (float)(1.0 / std::sqrt((double)m->L)), (int64_t)n, st));   // d skip of every block
   }
+  ready("skip_projection.", "output_projection.");
   // ---- blocks in reverse; gx = d loss / d x_{i+1}; x_L feeds nothing but the (discarded) last residual: gx starts at 0 ----
   float* gx = p.GXa;
   float* gx_prev = p.GXb;
@@ -593,6 +613,7 @@ extern "C" int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, cons
       r.precision = prec;
       DMEL_TRY(launch_conv(t.pre_dx, r, st));
     }
+    ready(pk);      // every gradient of block i is enqueued: its bucket can leave while blocks i-1 ... 0 still run
     std::swap(gx, gx_prev);
   }
   // ---- head: x_0 = silu(U), U = in_proj(x) ----
@@ -607,6 +628,7 @@ extern "C" int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, cons
   } else if (dx) {
     DMEL_HIP(hipMemcpyAsync(dx, gx, n * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
+  ready("input_projection.");
   return DMEL_OK;
 }
 

@@ -162,35 +162,23 @@ class VQGAN(nn.Module):
         assert gradient_clip_algorithm == "norm"
         torch.nn.utils.clip_grad_norm_([p for grp in optimizer.param_groups for p in grp["params"]], gradient_clip_val)
 
-    @staticmethod
-    def sync_gradients(optimizer, bucket_bytes: int = 64 << 20):
-        """The exchange step of data-parallel training: average the gradients of `optimizer`'s parameters over the ranks of the default
-        process group (RCCL on the GPUs: backend "nccl"), as Lightning's DDP does during manual_backward in the reference
-        (train_codec.py:49-55; SURVEY.md section 8(e): G side 438 MB + D side 37.5 MB in fp32, twice per step).  Gradients are
-        flattened into buckets of `bucket_bytes` (xGMI rings are per-link bound: few, large messages) and all-reduced in place.
-        No-op without an initialised process group or with a single rank."""
-        import torch.distributed as dist
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-            return
-        from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
-        world = dist.get_world_size()
-        grads = [p.grad for grp in optimizer.param_groups for p in grp["params"] if p.grad is not None]
-        bucket, size = [], 0
-        buckets = []
-        for g in grads:
-            bucket.append(g)
-            size += g.numel() * g.element_size()
-            if size >= bucket_bytes:
-                buckets.append(bucket)
-                bucket, size = [], 0
-        if bucket:
-            buckets.append(bucket)
-        for bk in buckets:
-            flat = _flatten_dense_tensors(bk)
-            dist.all_reduce(flat)
-            flat.div_(world)
-            for g, r in zip(bk, _unflatten_dense_tensors(flat, bk)):
-                g.copy_(r)
+    @property
+    def grad_reducer(self):
+        """The exchange step of data-parallel training (what Lightning's DDP wrapper does during manual_backward in the reference,
+        train_codec.py:49-55): dmel_codec_amd.ddp.GradReducer -- in-place RCCL all-reduce of the native flat gradient buffers, one
+        bucket per decoder WaveNet block, issued from inside backward in reverse layer order and waited for before the clip.
+        Inactive (gradients flow through autograd as usual) without an initialised process group or with a single rank."""
+        if getattr(self, "_grad_reducer", None) is None:
+            from ..ddp import GradReducer
+            self._grad_reducer = GradReducer()
+        return self._grad_reducer
+
+    def on_save_checkpoint(self, checkpoint):
+        """codec_lit_modules.py:114-119: the (frozen, separately distributed) vocoder is not saved with the codec."""
+        state_dict = checkpoint["state_dict"]
+        for name in list(state_dict.keys()):
+            if "vocoder" in name:
+                state_dict.pop(name)
 
     def log(self, name, value, **_):
         if not hasattr(self, "logged"):
@@ -219,9 +207,14 @@ class VQGAN(nn.Module):
         loss_fake = avg_with_mask(fake_logits ** 2, d_mask)
         loss_d = (loss_real + loss_fake) / self.accumulate_grad
         self.log("train/discriminator/loss", loss_d * self.accumulate_grad, batch_size=batch_size)
+        # gradients are exchanged once per optimiser step, on the accumulated sum (averaging is linear: same result as the
+        # reference's reduction after every backward)
+        last_micro_batch = (batch_idx + 1) % self.accumulate_grad == 0
+        if last_micro_batch:
+            self.grad_reducer.arm([self.discriminator])
         self.manual_backward(loss_d)
-        if (batch_idx + 1) % self.accumulate_grad == 0:
-            self.sync_gradients(optim_d)
+        if last_micro_batch:
+            self.grad_reducer.finish(optim_d)
             self.clip_gradients(optim_d, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
             optim_d.step()
             optim_d.zero_grad()
@@ -234,9 +227,13 @@ class VQGAN(nn.Module):
         self.log("train/generator/loss_vq", loss_vq, batch_size=batch_size)
         self.log("train/generator/loss_mel", loss_mel, batch_size=batch_size)
         self.log("train/generator/loss_adv", loss_adv, batch_size=batch_size)
+        if last_micro_batch:
+            # the discriminator is NOT armed here: like in the reference, this backward leaves gradients on its parameters that are
+            # only consumed (and exchanged, as part of the sum) by the next discriminator step
+            self.grad_reducer.arm([self.encoder, self.quantizer, self.decoder])
         self.manual_backward(loss)                                                                               # :315
-        if (batch_idx + 1) % self.accumulate_grad == 0:
-            self.sync_gradients(optim_g)
+        if last_micro_batch:
+            self.grad_reducer.finish(optim_g)
             self.clip_gradients(optim_g, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
             optim_g.step()
             optim_g.zero_grad()

@@ -26,13 +26,17 @@ class NativeModule(nn.Module):
         self._handle_versions = None
         self._ws = _lib.Workspace()
         self._precision = 0
+        self._generation = 0          # bumped whenever the native weight images change (rebuild or device-side re-pack)
+        self._grad_sink = None        # armed by ddp.GradReducer for the duration of one backward pass
+        self._pending_train = 0       # training forwards whose backward has not run yet
 
     # -- handle life cycle ---------------------------------------------------------------------
     def _native_state(self) -> dict:
         return self.state_dict()
 
     def _versions(self):
-        return tuple((id(t), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        # the device is part of the key: module.to(other_device) keeps ids and versions but the handle's buffers live on the old one
+        return tuple((id(t), t._version, str(t.device)) for t in list(self.parameters()) + list(self.buffers()))
 
     def _create_native(self) -> int:
         raise NotImplementedError
@@ -48,7 +52,7 @@ class NativeModule(nn.Module):
             # only the VALUES of CUDA parameters changed (an optimiser step): re-pack the existing handle's weight images on the
             # device instead of rebuilding the handle through the host
             old = self._handle_versions
-            same = old is not None and len(old) == len(ver) and all(a[0] == b[0] for a, b in zip(old, ver))
+            same = old is not None and len(old) == len(ver) and all(a[0] == b[0] and a[2] == b[2] for a, b in zip(old, ver))
             items = self._native_state_refs()
             if same and items and all(v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() for _, v in items):
                 keys = (C.c_char_p * len(items))(*[k.encode() for k, _ in items])
@@ -57,6 +61,7 @@ class NativeModule(nn.Module):
                     _lib.check(getattr(_lib.lib(), self._refresh_symbol)(self._handle, len(items), keys, ptrs, _lib.stream_ptr()),
                                f"{type(self).__name__}.refresh")
                 self._handle_versions = ver
+                self._generation += 1
                 return self._handle
         if self._handle is None or ver != self._handle_versions:
             self._free_native()
@@ -71,7 +76,51 @@ class NativeModule(nn.Module):
                 getattr(L, self._destroy_symbol)(h)
                 raise
             self._handle, self._handle_versions = h, ver
+            self._generation += 1
         return self._handle
+
+    # -- training calls: shared bookkeeping of the autograd Functions ---------------------------
+    def _begin_train_call(self, ctx) -> None:
+        """Called by a training Function's forward after module.native(): remembers which weight images the saved activations
+        belong to.  An optimiser step between this forward and its backward re-packs the images in place (same handle address), which
+        torch autograd would report as an in-place modification; the generation counter makes the native backward report it too."""
+        ctx.generation = self._generation
+        self._pending_train += 1
+
+    def _check_train_call(self, ctx) -> None:
+        if self._generation != ctx.generation or self._handle is None:
+            self._pending_train = max(0, self._pending_train - 1)
+            raise RuntimeError(f"{type(self).__name__}: parameters changed (optimiser step / load_state_dict / .to()) between a "
+                               "training forward and its backward")
+
+    def _deliver_grads(self, flat: torch.Tensor, slots, needs, streamed: bool = False):
+        """Hand the flat native gradient buffer to autograd -- or, while a ddp.GradReducer is armed on this module, straight to the
+        parameters and the reducer.  slots: [(parameter, offset, numel)] in the order of the Function's parameter inputs.
+        Unarmed: returns one view of `flat` per parameter (autograd accumulates them as usual).
+        Armed: parameter gradients become VIEWS of `flat` (earlier gradients are added into it first), `flat` is submitted to the
+        reducer once the last outstanding backward of this module has run, and autograd receives None for the parameters -- the
+        all-reduce works in place on the buffer the optimiser will read, no flatten / copy-back passes.  streamed=True: the C side
+        already submitted every region of `flat` through the on_ready hook."""
+        self._pending_train = max(0, self._pending_train - 1)
+        views = [flat[o:o + n].view(p.shape) if need else None for (p, o, n), need in zip(slots, needs)]
+        sink = self._grad_sink
+        if sink is None:
+            return views
+        for (p, _, _), v in zip(slots, views):
+            if v is None:
+                continue
+            if p.grad is not None:
+                v.add_(p.grad)
+            p.grad = v
+        if not streamed and self._pending_train == 0:
+            sink.submit(flat)
+        return [None] * len(views)
+
+    def _can_stream_grads(self, params, needs) -> bool:
+        """Per-block submission from inside the native backward is possible when this is the module's only outstanding backward and
+        no earlier gradient has to be added into the buffer first."""
+        return (self._grad_sink is not None and self._pending_train == 1 and all(needs)
+                and all(p.grad is None for p in params))
 
     def set_precision(self, precision) -> None:
         """"fp32" (default; the parity path), "fp32_mfma" (force the native fp32 MFMA kernel) or "bf16": convolution operands

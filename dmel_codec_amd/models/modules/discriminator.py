@@ -27,13 +27,13 @@ class _DiscTrainFn(torch.autograd.Function):
             _lib.check(L.dmel_discriminator_forward_train(h, x.data_ptr(), y.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
                                                           _lib.stream_ptr()), "discriminator_forward_train")
         ctx.module, ctx.handle, ctx.ws, ctx.shape = module, h, ws, (B, H, W)
+        module._begin_train_call(ctx)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         module, h, ws = ctx.module, ctx.handle, ctx.ws
-        if module._handle != h:
-            raise RuntimeError("discriminator parameters changed between forward and backward")
+        module._check_train_call(ctx)
         L = _lib.lib()
         B, H, W = ctx.shape
         dy = dy.float().contiguous()
@@ -42,14 +42,12 @@ class _DiscTrainFn(torch.autograd.Function):
             flat = torch.empty(L.dmel_discriminator_grad_floats(h), dtype=torch.float32, device=dy.device)
             _lib.check(L.dmel_discriminator_backward(h, dy.data_ptr(), _lib.ptr(dx), flat.data_ptr(), B, H, W, ws.data_ptr(), ws.numel(),
                                                      _lib.stream_ptr()), "discriminator_backward")
-        grads = []
+        slots = []
         off, num = C.c_int64(), C.c_int64()
-        for (key, prm), need in zip(module.named_parameters(), ctx.needs_input_grad[2:]):
-            if not need:
-                grads.append(None)
-                continue
+        for key, prm in module.named_parameters():
             _lib.check(L.dmel_discriminator_grad_slot(h, key.encode(), C.byref(off), C.byref(num)), "discriminator_grad_slot")
-            grads.append(flat[off.value:off.value + num.value].view(prm.shape))
+            slots.append((prm, off.value, num.value))
+        grads = module._deliver_grads(flat, slots, ctx.needs_input_grad[2:])
         return (None, dx, *grads)
 
 

@@ -58,6 +58,7 @@ class _QuantizerTrainFn(torch.autograd.Function):
             _lib.check(L.dmel_quantizer_forward_train(h, z.data_ptr(), zq.data_ptr(), ids.data_ptr(), lat.data_ptr(), B, T, ws.data_ptr(),
                                                       ws.numel(), _lib.stream_ptr()), "quantizer_forward_train")
         ctx.module, ctx.handle, ctx.ws = module, h, ws
+        module._begin_train_call(ctx)
         ctx.save_for_backward(z)
         ctx.mark_non_differentiable(ids, lat)
         return zq, ids, lat
@@ -66,8 +67,7 @@ class _QuantizerTrainFn(torch.autograd.Function):
     def backward(ctx, dzq, _dids, _dlat):
         module, h, ws = ctx.module, ctx.handle, ctx.ws
         (z,) = ctx.saved_tensors
-        if module._handle != h:
-            raise RuntimeError("quantiser parameters changed between forward and backward")
+        module._check_train_call(ctx)
         L = _lib.lib()
         B, T = z.shape[0] // module.groups, z.shape[2]
         dzq = dzq.float().contiguous()
@@ -76,14 +76,12 @@ class _QuantizerTrainFn(torch.autograd.Function):
             flat = torch.empty(L.dmel_quantizer_grad_floats(h), dtype=torch.float32, device=z.device)
             _lib.check(L.dmel_quantizer_backward(h, z.data_ptr(), dzq.data_ptr(), dz.data_ptr(), flat.data_ptr(), B, T, ws.data_ptr(),
                                                  ws.numel(), _lib.stream_ptr()), "quantizer_backward")
-        grads = []
+        slots = []
         off, num = C.c_int64(), C.c_int64()
-        for (key, prm), need in zip(module.named_parameters(), ctx.needs_input_grad[2:]):
-            if not need:
-                grads.append(None)
-                continue
+        for key, prm in module.named_parameters():
             _lib.check(L.dmel_quantizer_grad_slot(h, key.encode(), C.byref(off), C.byref(num)), "quantizer_grad_slot")
-            grads.append(flat[off.value:off.value + num.value].view(prm.shape))
+            slots.append((prm, off.value, num.value))
+        grads = module._deliver_grads(flat, slots, ctx.needs_input_grad[2:])
         return (None, dz if ctx.needs_input_grad[1] else None, *grads)
 
 

@@ -39,6 +39,7 @@ class _ConvNeXtTrainFn(torch.autograd.Function):
             _lib.check(L.dmel_convnext_forward_train(h, x.data_ptr(), y.data_ptr(), N, T, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
                        "convnext_forward_train")
         ctx.module, ctx.handle, ctx.ws = module, h, ws
+        module._begin_train_call(ctx)
         ctx.save_for_backward(x)
         return y
 
@@ -46,8 +47,7 @@ class _ConvNeXtTrainFn(torch.autograd.Function):
     def backward(ctx, dy):
         module, h, ws = ctx.module, ctx.handle, ctx.ws
         (x,) = ctx.saved_tensors
-        if module._handle != h:
-            raise RuntimeError("ConvNeXtBlock parameters changed between forward and backward")
+        module._check_train_call(ctx)
         L = _lib.lib()
         N, _, T = x.shape
         dy = dy.float().contiguous()
@@ -56,14 +56,12 @@ class _ConvNeXtTrainFn(torch.autograd.Function):
             flat = torch.empty(L.dmel_convnext_grad_floats(h), dtype=torch.float32, device=x.device)
             _lib.check(L.dmel_convnext_backward(h, x.data_ptr(), dy.data_ptr(), dx.data_ptr(), flat.data_ptr(), N, T, ws.data_ptr(),
                                                 ws.numel(), _lib.stream_ptr()), "convnext_backward")
-        grads = []
+        slots = []
         off, num = C.c_int64(), C.c_int64()
-        for (key, prm), need in zip(module.named_parameters(), ctx.needs_input_grad[2:]):
-            if not need:
-                grads.append(None)
-                continue
+        for key, prm in module.named_parameters():
             _lib.check(L.dmel_convnext_grad_slot(h, key.encode(), C.byref(off), C.byref(num)), "convnext_grad_slot")
-            grads.append(flat[off.value:off.value + num.value].view(prm.shape))
+            slots.append((prm, off.value, num.value))
+        grads = module._deliver_grads(flat, slots, ctx.needs_input_grad[2:])
         return (None, dx if ctx.needs_input_grad[1] else None, *grads)
 
 

@@ -70,6 +70,7 @@ class _WaveNetTrainFn(torch.autograd.Function):
             _lib.check(L.dmel_wavenet_forward_train(h, x.data_ptr(), _lib.ptr(condition), y.data_ptr(), N, T, ws.data_ptr(),
                                                     ws.numel(), _lib.stream_ptr()), "wavenet_forward_train")
         ctx.module, ctx.handle, ctx.ws = module, h, ws
+        module._begin_train_call(ctx)
         ctx.save_for_backward(x, condition if condition is not None else torch.empty(0, device=dev))
         ctx.has_cond = condition is not None
         return y
@@ -79,8 +80,7 @@ class _WaveNetTrainFn(torch.autograd.Function):
         module, h, ws = ctx.module, ctx.handle, ctx.ws
         x, cond = ctx.saved_tensors
         cond = cond if ctx.has_cond else None
-        if module._handle != h:
-            raise RuntimeError("WaveNet parameters changed between forward and backward")
+        module._check_train_call(ctx)
         L = _lib.lib()
         N, _, T = x.shape
         dev = x.device
@@ -88,19 +88,37 @@ class _WaveNetTrainFn(torch.autograd.Function):
         need_dx, need_dc = ctx.needs_input_grad[1], ctx.has_cond and ctx.needs_input_grad[2]
         dx = torch.empty_like(x) if need_dx else None
         dc = torch.empty_like(cond) if need_dc else None
+        trained = module._trained_parameters()
+        needs = ctx.needs_input_grad[3:]
+        # data-parallel training: while a ddp.GradReducer is armed, every block's slice of the flat gradient buffer leaves for its
+        # all-reduce from INSIDE the native backward (on_ready fires when the block's last kernel is enqueued), so the exchange of
+        # block k overlaps the backward of blocks k-1 ... 0
+        stream_out = module._can_stream_grads([p for _, p in trained], needs)
+        failure = []
         with torch.cuda.device(dev):
             flat = torch.empty(L.dmel_wavenet_grad_floats(h), dtype=torch.float32, device=dev)
-            _lib.check(L.dmel_wavenet_backward(h, x.data_ptr(), _lib.ptr(cond), dy.data_ptr(), _lib.ptr(dx), _lib.ptr(dc),
-                                               flat.data_ptr(), N, T, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
+            hook = None
+            if stream_out:
+                sink = module._grad_sink
+
+                def on_ready(_user, offset, numel):
+                    try:
+                        sink.submit(flat[offset:offset + numel])
+                    except BaseException as e:      # never unwind through the C frame
+                        failure.append(e)
+                hook = _lib.GRAD_READY_FN(on_ready)
+            _lib.check(L.dmel_wavenet_backward_hooked(h, x.data_ptr(), _lib.ptr(cond), dy.data_ptr(), _lib.ptr(dx), _lib.ptr(dc),
+                                                      flat.data_ptr(), N, T, ws.data_ptr(), ws.numel(), _lib.stream_ptr(),
+                                                      hook if hook is not None else _lib.GRAD_READY_FN(), None),
                        "wavenet_backward")
-        grads = []
+        if failure:
+            raise failure[0]
+        slots = []
         off, num = C.c_int64(), C.c_int64()
-        for (key, prm), need in zip(module._trained_parameters(), ctx.needs_input_grad[3:]):
-            if not need:
-                grads.append(None)
-                continue
+        for key, prm in trained:
             _lib.check(L.dmel_wavenet_grad_slot(h, key.encode(), C.byref(off), C.byref(num)), "wavenet_grad_slot")
-            grads.append(flat[off.value:off.value + num.value].view(prm.shape))
+            slots.append((prm, off.value, num.value))
+        grads = module._deliver_grads(flat, slots, needs, streamed=stream_out)
         return (None, dx, dc, *grads)
 
 

@@ -1,7 +1,19 @@
-"""Mask helpers of the codec path.  Mirrors dmel_codec/utils/utils.py:48-67 (reference)."""
+"""Mask helpers of the codec path and the checkpoint finder of train_codec.py.  Mirrors dmel_codec/utils/utils.py:11-21,48-67
+(reference)."""
 from __future__ import annotations
 
+import glob
+import os
+
 import torch
+
+
+def find_lastest_ckpt(directory):
+    """utils/utils.py:11-21 (name spelled as there): newest `*.ckpt` of `directory` by modification time, or None."""
+    if directory is None:
+        return None
+    found = glob.glob(os.path.join(directory, "*.ckpt"))
+    return max(found, key=os.path.getmtime) if found else None
 
 
 def sequence_mask(length: torch.Tensor, max_length: int | None = None) -> torch.Tensor:

@@ -138,6 +138,17 @@ int dmel_wavenet_forward_train(const dmel_wavenet* m, const float* x, const floa
 int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, const float* condition, const float* dy, float* dx /*nullable*/,
                           float* dcondition /*nullable*/, float* grads, int N, int64_t T, void* workspace, size_t workspace_bytes,
                           void* stream);
+/* The exchange step of data-parallel training (the reference gets it from Lightning's DDP wrapper, config/codec/dMel_example.yaml:14:
+ * gradient buckets are all-reduced while backward is still running).  dmel_wavenet_backward_hooked is dmel_wavenet_backward that calls
+ * `on_ready(user, offset, numel)` on the calling host thread right after it has ENQUEUED the last kernel that writes
+ * grads[offset, offset + numel): first the tail (skip_projection + output_projection), then residual_layers L-1 ... 0 (one contiguous
+ * region per block: the bucket SURVEY section 8(e) asks for), then input_projection.  The regions are disjoint and cover the whole
+ * buffer.  A caller that records an event on `stream` inside the callback and lets a communication stream wait for it overlaps the
+ * all-reduce of block k with the backward of blocks k-1 ... 0.  on_ready == NULL: plain dmel_wavenet_backward. */
+typedef void (*dmel_grad_ready_fn)(void* user, int64_t offset, int64_t numel);
+int dmel_wavenet_backward_hooked(const dmel_wavenet* m, const float* x, const float* condition, const float* dy, float* dx /*nullable*/,
+                                 float* dcondition /*nullable*/, float* grads, int N, int64_t T, void* workspace,
+                                 size_t workspace_bytes, void* stream, dmel_grad_ready_fn on_ready, void* user);
 
 /* ConvNeXtBlock (models/modules/firefly.py:337-402; C-ABI row `convnext_block`), standalone: y = x + gamma * pwconv2(gelu(pwconv1(
  * LayerNorm_C(dwconv7(x))))), x / y (N, dim, T).  set_tensor keys: dwconv.weight (dim,1,7), dwconv.bias, norm.weight, norm.bias,

@@ -54,38 +54,116 @@ def test_single_process_helpers():
     assert torch.equal(a, bench.synth_audio(2, 1000, 7))
 
 
-def _grad_worker(rank: int, world: int, port: int, out):
+def _reducer_worker(rank: int, world: int, port: int, out):
+    """A stand-in for a native module on the CPU: same bookkeeping (NativeModule._begin_train_call / _can_stream_grads /
+    _deliver_grads), a backward that fills ONE flat gradient buffer block by block in reverse order and hands each block to the
+    reducer as soon as it is complete -- exactly what dmel_wavenet_backward_hooked's on_ready callback does on the GPU."""
     sys.path.insert(0, ROOT)
-    from dmel_codec_amd.models.codec_lit_modules import VQGAN
+    from dmel_codec_amd.ddp import GradReducer
+    from dmel_codec_amd.models.modules._native import NativeModule
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.manual_seed(0)
-        params = [torch.nn.Parameter(torch.zeros(n)) for n in (7, 1000, 3, 50000)]       # several buckets at bucket_bytes = 4096
-        for i, p in enumerate(params):
-            p.grad = torch.full_like(p, float(rank + 1) * (i + 1))
-        params.append(torch.nn.Parameter(torch.zeros(5)))                                # no gradient: skipped
-        opt = torch.optim.SGD(params, lr=0.1)
-        VQGAN.sync_gradients(opt, bucket_bytes=4096)
-        out.put((rank, [float(p.grad[0]) for p in params[:4]], [float(p.grad.min()) == float(p.grad.max()) for p in params[:4]],
-                 params[4].grad is None))
+        L, n = 4, 1000
+        events = []
+
+        class Blocks(NativeModule):
+            def __init__(self):
+                super().__init__()
+                self.w = torch.nn.ParameterList([torch.nn.Parameter(torch.zeros(n)) for _ in range(L)])
+                self.dead = torch.nn.Parameter(torch.zeros(3))      # like diffusion_projection: never receives a gradient
+
+            def trained(self):
+                return list(self.w)
+
+            def forward(self, x):
+                return _Fn.apply(self, x, *self.trained())
+
+        class _Fn(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, module, x, *params):
+                ctx.module = module
+                module._begin_train_call(ctx)
+                ctx.save_for_backward(x)
+                return x.sum() * 0 + sum((p * x[: p.numel()]).sum() for p in params)
+
+            @staticmethod
+            def backward(ctx, dy):
+                module = ctx.module
+                (x,) = ctx.saved_tensors
+                module._check_train_call(ctx)
+                params = module.trained()
+                needs = ctx.needs_input_grad[2:]
+                stream_out = module._can_stream_grads(params, needs)
+                flat = torch.empty(L * n)
+                for k in reversed(range(L)):                        # reverse layer order
+                    flat[k * n:(k + 1) * n] = x[:n] * dy * (k + 1)
+                    events.append(("computed", k))
+                    if stream_out:
+                        module._grad_sink.submit(flat[k * n:(k + 1) * n])
+                grads = module._deliver_grads(flat, [(p, k * n, n) for k, p in enumerate(params)], needs, streamed=stream_out)
+                return (None, None, *grads)
+
+        m = Blocks()
+        object.__setattr__(m, "_handle", 1)                          # "a native handle exists"
+        extra = torch.nn.Linear(1, 2)                                # torch-native parameter (like quality_projection)
+        unused = torch.nn.Parameter(torch.zeros(4))                  # no gradient on any rank: must stay None
+        opt = torch.optim.SGD(list(m.parameters()) + list(extra.parameters()) + [unused], lr=0.1)
+        red = GradReducer()
+        red.record_events = True
+        red.events = events
+        x = torch.full((n,), float(rank + 1))
+        # ---- pass 1: one backward through the module, per-block submission overlapped with the rest of backward
+        red.arm([m])
+        (m(x) + extra(torch.ones(1)).sum() * (rank + 1)).backward()
+        red.finish(opt)
+        order1 = list(events)
+        g1 = [float(p.grad[0]) for p in m.w]
+        uniform1 = all(float(p.grad.min()) == float(p.grad.max()) for p in m.w)
+        extra_g = [float(extra.weight.grad[0, 0]), float(extra.bias.grad[1])]
+        # ---- pass 2: gradients already present + two uses of the module in one graph (the discriminator on real and fake mels)
+        events.clear()
+        red.arm([m])
+        (m(x) + 2 * m(x)).backward()
+        red.finish(opt)
+        order2 = list(events)
+        g2 = [float(p.grad[0]) for p in m.w]
+        # ---- unarmed: plain autograd accumulation (single-rank behaviour)
+        opt.zero_grad()
+        m(x).backward()
+        g3 = [float(p.grad[0]) for p in m.w]
+        out.put((rank, order1, g1, uniform1, extra_g, unused.grad is None, m.dead.grad is None, order2, g2, g3, m._pending_train))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def test_gradient_exchange_step_two_ranks():
-    """VQGAN.sync_gradients (the one collective of the training path: bucketed all-reduce + average, RCCL on the GPUs) over gloo."""
+def test_gradient_exchange_overlaps_backward_two_ranks():
+    """dmel_codec_amd.ddp.GradReducer over gloo: per-block in-place all-reduce issued from inside backward in reverse layer order (a
+    block's collective is issued BEFORE the remaining blocks are differentiated), averaged values, static collectives (a parameter
+    without gradient on every rank keeps None), accumulation into existing gradients, modules used twice in one graph."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_reducer_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=180) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, firsts, uniform, untouched in res:
-        assert firsts == [1.5 * (i + 1) for i in range(4)]        # mean of (1, 2) * (i + 1) on both ranks
-        assert all(uniform) and untouched
+    L, n = 4, 1000
+    for rank, order1, g1, uniform1, extra_g, unused_none, dead_none, order2, g2, g3, pending in res:
+        # pass 1: computed(3), issue, computed(2), issue, ... : block k is on the wire before block k-1 is differentiated
+        assert order1[0] == ("arm", 1)
+        body = order1[1:1 + 2 * L]
+        assert body == [e for k in reversed(range(L)) for e in (("computed", k), ("issue", n))], body
+        assert order1[-2][0] == "issue_rest" and order1[-1] == ("finish", L)
+        assert g1 == [1.5 * (k + 1) for k in range(L)] and uniform1          # mean over ranks of (rank + 1) * (k + 1)
+        assert extra_g == [1.5, 1.5] and unused_none and dead_none
+        # pass 2: nothing leaves until the module's last outstanding backward; then ONE message holding old + both new gradients
+        issues = [e for e in order2 if e[0] == "issue"]
+        assert issues == [("issue", L * n)]
+        assert order2.index(("issue", L * n)) > max(i for i, e in enumerate(order2) if e[0] == "computed")
+        assert g2 == [1.5 * (k + 1) * 4 for k in range(L)]                   # avg(old) + avg(1 + 2 uses)
+        assert g3 == [float(rank + 1) * (k + 1) for k in range(L)] and pending == 0
