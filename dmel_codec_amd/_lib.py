@@ -94,6 +94,7 @@ PROTOTYPES = {
     "dmel_wavenet_forward": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int64, vp, vp, C.c_int, vp, C.c_size_t, vp]),
     "dmel_quantizer_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int]),
     "dmel_quantizer_destroy": (None, [vp]),
+    "dmel_quantizer_set_strict": (C.c_int, [vp, C.c_int]),
     "dmel_quantizer_set_tensor": (C.c_int, [vp, C.c_char_p, vp, i64p, C.c_int]),
     "dmel_quantizer_finalize": (C.c_int, [vp]),
     "dmel_quantizer_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),

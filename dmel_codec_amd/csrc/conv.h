@@ -86,6 +86,10 @@ struct ConvRun {
   float* skip = nullptr;          // RESSKIP
   int skip_first = 0;
   int precision = 0;              // DMEL_PRECISION_* (include/dmel_hip.h)
+  // Folded batch ("B = 1" launches over a (C, N * fold_pitch) buffer that holds N short items side by side, fold_valid real columns
+  // each followed by fold_pitch - fold_valid ZERO columns that play the role of the convolution's zero padding): outputs in the gap
+  // columns are written as zeros so the invariant survives the layer.  0 = off.
+  int fold_pitch = 0, fold_valid = 0;
 };
 
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream);

@@ -51,6 +51,7 @@ struct KArgs {
   const float* row_scale;
   const int64_t* out_len;
   float* skip;
+  int fold_pitch, fold_valid;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -61,6 +62,11 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     case ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
     default: return v;
   }
+}
+
+// folded batch (ConvRun::fold_pitch): is output column q one of the zero columns between two items?
+__device__ __forceinline__ bool in_gap(const KArgs& a, int q) {
+  return a.fold_pitch > 0 && (q % a.fold_pitch) >= a.fold_valid;
 }
 
 // ------------------------------------------------------------------ epilogue (shared by both kernels)
@@ -85,7 +91,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         colok[ni] = colbase + ni * 32 < tlim;
-        live[ni] = colbase + ni * 32 < olim;
+        live[ni] = colbase + ni * 32 < olim && !in_gap(a, colbase + ni * 32);
         cq[ni] = min(colbase + ni * 32, tlim - 1);
       }
 #pragma unroll
@@ -152,7 +158,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
           if (rrow) v += rrow[t];
           if (a.accumulate) v += yrow[t];
           if (a.out_div != 1.f) v = v / a.out_div;
-          if (t >= olim) v = 0.f;
+          if (t >= olim || in_gap(a, q)) v = 0.f;
           yrow[t] = v;
         }
       }
@@ -161,6 +167,9 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
     float* yb = a.y + (int64_t)b * a.y_bs;
     float* sb = (MODE == EPI_RESSKIP) ? a.skip + (int64_t)b * a.y_bs : nullptr;
     const int ycs = (int)a.y_cs;
+    bool gap[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) gap[ni] = in_gap(a, colbase + ni * 32);
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int mtile = mrow0 + mi * 32;
@@ -182,10 +191,10 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
           const float v0 = acc[mi][ni][r] + b0;
           const float v1 = acc[mi][ni][(r + 4) & 15] + b1;
           if (MODE == EPI_GATE) {
-            yrow[q] = (1.f / (1.f + expf(-v0))) * tanhf(v1);
+            yrow[q] = gap[ni] ? 0.f : (1.f / (1.f + expf(-v0))) * tanhf(v1);
           } else {
-            yrow[q] = (yrow[q] + v0) / 1.41421356237309504880f;
-            srow[q] = a.skip_first ? v1 : srow[q] + v1;
+            yrow[q] = gap[ni] ? 0.f : (yrow[q] + v0) / 1.41421356237309504880f;
+            srow[q] = gap[ni] ? 0.f : (a.skip_first ? v1 : srow[q] + v1);
           }
         }
       }
@@ -925,6 +934,9 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   ka.y = r.y; ka.y_bs = r.y_bs; ka.y_cs = r.y_cs; ka.Tout = r.Tout > 0 ? r.Tout : r.Tcols * r.out_tstride;
   ka.res = r.res; ka.res_bs = r.res_bs; ka.res_cs = r.res_cs; ka.row_scale = r.row_scale;
   ka.out_len = r.out_len; ka.skip = r.skip;
+  ka.fold_pitch = r.fold_pitch; ka.fold_valid = r.fold_valid;
+  DMEL_CHECK_ARG(r.fold_pitch == 0 || (r.fold_pitch >= r.fold_valid && r.fold_valid > 0 && r.B == 1 && r.out_tstride == 1),
+                 "conv: folded-batch launches are single-item, unit-stride and need 0 < fold_valid <= fold_pitch");
   DMEL_CHECK_ARG((int64_t)d.C * ka.y_cs < ((int64_t)1 << 31) && ka.Tout < ((int64_t)1 << 30) && ka.Tcols < ((int64_t)1 << 30),
                  "conv: one batch item of the output exceeds 32-bit offsets");
   ka.mtiles = pc.Mpad / 32;

@@ -325,20 +325,104 @@ extern "C" int dmel_wavenet_finalize(dmel_wavenet* m) {
   return DMEL_OK;
 }
 
-static size_t wavenet_plan(const dmel_wavenet* m, int N, int64_t T, void* ws, float** xb, float** zb, float** sb, float** tb) {
+// Folded batch: short items (1 s clips = 92 frames) leave the per-item tiling with 96-column tiles that do not divide the chip evenly
+// (decoder of cfg 2: 35 row tiles x 32 items = 1120 wave tiles on 1024 SIMDs -> two rounds, the second 9 % full).  Laying the N items
+// side by side on ONE time axis, each followed by max-dilation zero columns (the convolution's zero padding, shared by neighbours),
+// turns every layer into a single long-row GEMM whose 128-column tiles pack the chip in one round (35 x 25 = 875 wave tiles).
+struct FoldGeom {
+  bool on = false;
+  int P = 0;                 // item pitch = T + gap
+  int64_t cols = 0, pitch = 0;
+};
+static FoldGeom wavenet_fold(const dmel_wavenet* m, int N, int64_t T) {
+  // Opt-in (DMEL_WAVENET_FOLD=1, read per call so one process can A/B it): measured on the decoder of cfg 2 (profiles/r02_wavenet_fold.txt)
+  // the folded launches are NOT faster with the current conv kernel -- 4.98 ms vs 4.12 ms per forward at the kernel's own tile choice,
+  // 4.11 ms when forced onto the same 128 x 96 tile: a lone wave per SIMD runs the K loop at ~45 % of its MFMA time, so trading two
+  // half-empty rounds for one full round of single waves gains nothing; what this shape needs is overlap inside a wave, not balance.
+  const char* e = getenv("DMEL_WAVENET_FOLD");
+  const int mode = e ? atoi(e) : 0;   // 0 off (default), 1 on
+  const int max_t = 384;
+  FoldGeom f;
+  const int maxdil = m->cycle ? 1 << std::min(m->L - 1, m->cycle - 1) : 1;
+  f.P = (int)T + maxdil;
+  f.cols = (int64_t)N * f.P;
+  f.pitch = (int64_t)align_up((size_t)f.cols, 32);
+  f.on = N >= 2 && f.cols < ((int64_t)1 << 28) && mode == 1 && T <= max_t;
+  return f;
+}
+
+struct WavePlan { float *xb, *zb, *sb, *tb, *cf, *xin, *yf; size_t bytes; };
+static WavePlan wavenet_plan(const dmel_wavenet* m, int N, int64_t T, void* ws) {
   Arena a(ws, (size_t)-1);
-  const size_t n = (size_t)N * m->C * T;
-  float* x = a.take<float>(n);
-  float* z = a.take<float>(n);
-  float* s = a.take<float>(n);
-  float* t = m->has_out ? a.take<float>(n) : nullptr;
-  if (xb) { *xb = x; *zb = z; *sb = s; *tb = t; }
-  return align_up(a.off, 256);
+  WavePlan p{};
+  const FoldGeom f = wavenet_fold(m, N, T);
+  const size_t n = f.on ? (size_t)m->C * f.pitch : (size_t)N * m->C * T;
+  p.xb = a.take<float>(n);
+  p.zb = a.take<float>(n);
+  p.sb = a.take<float>(n);
+  p.tb = m->has_out ? a.take<float>(n) : nullptr;
+  if (f.on) {
+    p.cf = m->Ccond ? a.take<float>((size_t)m->Ccond * f.pitch) : nullptr;
+    p.xin = m->has_in ? a.take<float>((size_t)m->Cin * f.pitch) : nullptr;
+    p.yf = m->has_out ? a.take<float>((size_t)m->Cout * f.pitch) : nullptr;
+  }
+  p.bytes = align_up(a.off, 256);
+  return p;
 }
 
 extern "C" size_t dmel_wavenet_workspace_bytes(const dmel_wavenet* m, int N, int64_t T) {
   if (!m || N <= 0 || T <= 0) return 0;
-  return wavenet_plan(m, N, T, nullptr, nullptr, nullptr, nullptr, nullptr);
+  return wavenet_plan(m, N, T, nullptr).bytes;
+}
+
+// one folded launch: input rows (Cin, pitch), output rows (Cout, pitch), all N items in one "batch item" of f.cols columns
+static ConvRun run_folded(const FoldGeom& f, const float* x, float* y, int64_t T) {
+  ConvRun r;
+  r.seg[0].x = x; r.seg[0].bstride = 0; r.seg[0].cstride = f.pitch; r.seg[0].Tin = f.cols;
+  r.B = 1; r.Tcols = f.cols; r.y = y; r.y_bs = 0; r.y_cs = f.pitch; r.Tout = f.cols;
+  r.fold_pitch = f.P; r.fold_valid = (int)T;
+  return r;
+}
+
+static int wavenet_forward_folded(const dmel_wavenet* m, const FoldGeom& f, const WavePlan& p, const float* x, const float* condition,
+                                  float* y, int N, int64_t T, const int64_t* in_lengths, const int64_t* out_lengths, int div,
+                                  hipStream_t st) {
+  const int C = m->C;
+  if (m->Ccond) DMEL_TRY(launch_fold(condition, p.cf, nullptr, 1, N, m->Ccond, T, f.P, f.pitch, st));
+  if (m->has_in) {  // wavenet.py:205-207
+    DMEL_TRY(launch_fold(x, p.xin, in_lengths, div, N, m->Cin, T, f.P, f.pitch, st));
+    ConvRun r = run_folded(f, p.xin, p.xb, T);
+    r.act = ACT_SILU; r.precision = m->precision;
+    DMEL_TRY(launch_conv(m->in_proj, r, st));
+  } else {
+    DMEL_TRY(launch_fold(x, p.xb, in_lengths, div, N, C, T, f.P, f.pitch, st));
+  }
+  for (int i = 0; i < m->L; ++i) {  // wavenet.py:116-135
+    ConvRun g = run_folded(f, p.xb, p.zb, T);
+    if (m->Ccond) { g.seg[1].x = p.cf; g.seg[1].bstride = 0; g.seg[1].cstride = f.pitch; g.seg[1].Tin = f.cols; }
+    g.precision = m->precision;
+    DMEL_TRY(launch_conv(m->gate[i], g, st));
+    ConvRun r = run_folded(f, p.zb, p.xb, T);
+    r.skip = p.sb; r.skip_first = (i == 0);
+    r.precision = m->precision;
+    DMEL_TRY(launch_conv(m->resskip[i], r, st));
+  }
+  {  // wavenet.py:218-223
+    float* proj = m->has_out ? p.tb : p.zb;
+    ConvRun r = run_folded(f, p.sb, proj, T);
+    r.seg[0].in_scale = (float)(1.0 / std::sqrt((double)m->L));
+    if (m->has_out) r.act = ACT_SILU;
+    r.precision = m->precision;
+    DMEL_TRY(launch_conv(m->skip_proj, r, st));
+    if (m->has_out) {
+      ConvRun o = run_folded(f, p.tb, p.yf, T);
+      o.precision = m->precision;
+      DMEL_TRY(launch_conv(m->out_proj, o, st));
+      proj = p.yf;
+    }
+    DMEL_TRY(launch_unfold(proj, y, out_lengths, div, N, m->Cout, T, f.P, f.pitch, st));
+  }
+  return DMEL_OK;
 }
 
 extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const float* condition, float* y, int N, int64_t T,
@@ -348,11 +432,13 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
   if (!m->ready) { set_error("wavenet_forward: handle not finalized"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG((m->Ccond != 0) == (condition != nullptr), "wavenet_forward: condition tensor does not match the configuration");
   DMEL_CHECK_ARG(N > 0 && T > 0, "wavenet_forward: bad shape");
-  float *xb, *zb, *sb, *tb;
-  const size_t need = wavenet_plan(m, N, T, workspace, &xb, &zb, &sb, &tb);
-  DMEL_CHECK_ARG(workspace_bytes >= need, "wavenet_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
+  const WavePlan p = wavenet_plan(m, N, T, workspace);
+  float *xb = p.xb, *zb = p.zb, *sb = p.sb, *tb = p.tb;
+  DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "wavenet_forward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
   hipStream_t st = (hipStream_t)stream;
   const int C = m->C, div = group_repeat > 0 ? group_repeat : 1;
+  const FoldGeom fold = wavenet_fold(m, N, T);
+  if (fold.on) return wavenet_forward_folded(m, fold, p, x, condition, y, N, T, in_lengths, out_lengths, div, st);
 
   if (m->has_in) {  // wavenet.py:205-207: 1x1 projection + SiLU
     ConvRun r = run_1seg(x, m->Cin, T, xb, C, T, N);
@@ -884,6 +970,11 @@ extern "C" int dmel_quantizer_create(dmel_quantizer** out, int input_dim, int n_
   if (rc != DMEL_OK) { delete q; return rc; }
   for (int i = 0; i < n_levels; ++i) q->levels[i] = levels[i];
   *out = q;
+  return DMEL_OK;
+}
+extern "C" int dmel_quantizer_set_strict(dmel_quantizer* q, int on) {
+  DMEL_CHECK_ARG(q, "NULL handle");
+  q->fk.strict = on != 0;
   return DMEL_OK;
 }
 extern "C" void dmel_quantizer_destroy(dmel_quantizer* q) { delete q; }

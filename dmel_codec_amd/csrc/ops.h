@@ -9,6 +9,7 @@ struct FsqConst {
   int levels[4], half_width[4], basis[4];
   float half_l[4], offset[4], shift[4];
   int prebound;
+  int strict;      // encode only: project_in and the bound(s) evaluated in float64 (dmel_quantizer_set_strict)
 };
 
 int make_fsq_const(FsqConst& k, const int* levels, int n, int prebound);
@@ -28,6 +29,11 @@ int launch_dwconv_ln(const float* x, float* y, const float* dw_w, const float* d
 int launch_conv_post(const float* x, float* y, const float* w_dev, float bias, int act, int B, int C, int K, int64_t T,
                      hipStream_t s);
 int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, int N, int C, int64_t T, hipStream_t s);
+// Folded batch of short items (see ConvRun::fold_pitch): xf (C, pitch) holds item n's T columns at [n*P, n*P + T), zeros elsewhere.
+// fold: xf[c][n*P + t] = x[n][c][t] * (t < len[n / div]) (len nullable), every other column of the `pitch`-wide rows zeroed.
+// unfold: y[n][c][t] = xf[c][n*P + t] * (t < len[n / div]).
+int launch_fold(const float* x, float* xf, const int64_t* len, int div, int N, int C, int64_t T, int P, int64_t pitch, hipStream_t s);
+int launch_unfold(const float* xf, float* y, const int64_t* len, int div, int N, int C, int64_t T, int P, int64_t pitch, hipStream_t s);
 int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host, int logscale,
                     int B, int C, int64_t T, hipStream_t s);
 

@@ -102,6 +102,33 @@ __global__ __launch_bounds__(256) void fsq_encode_kernel(const float* __restrict
     for (int j = 0; j < 4; ++j)
       if (j < k.n_levels) acc[j] = fmaf(w_in[((int64_t)g * k.n_levels + j) * C + c], v, acc[j]);
   }
+  if (k.strict) {
+    // strict mode: the last Linear and the bound(s) in float64, so that the value that is rounded does not depend on a summation
+    // order or on a tanhf implementation -- two implementations fed the same features produce the same ids (the CPU oracle's strict
+    // restatement does exactly this).  70 x 3 double FMAs per token: free.
+    double dacc[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < C; ++c) {
+      const double v = (double)zr[(int64_t)c * T4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (j < k.n_levels) dacc[j] = fma((double)w_in[((int64_t)g * k.n_levels + j) * C + c], v, dacc[j]);
+    }
+    int sid = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (j < k.n_levels) {
+        double v = dacc[j] + (double)b_in[g * k.n_levels + j];
+        const double hl = (double)k.half_l[j], of = (double)k.offset[j], sh = atanh(of / hl);   // shift in float64 too
+        if (k.prebound) v = tanh(v + sh) * hl - of;
+        v = tanh(v + sh) * hl - of;
+        const float vf = (float)v;
+        if (prequant) prequant[(((int64_t)g * B + b) * T4 + l) * k.n_levels + j] = vf;
+        sid += ((int)rintf(vf) + k.half_width[j]) * k.basis[j];
+      }
+    }
+    ids[i] = sid;
+    return;
+  }
   int id = 0;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -264,6 +291,7 @@ int make_fsq_const(FsqConst& k, const int* levels, int n, int prebound) {
   DMEL_CHECK_ARG(n >= 1 && n <= 4, "FSQ: 1..4 levels supported, got %d", n);
   k.n_levels = n;
   k.prebound = prebound;
+  k.strict = 0;
   int basis = 1;
   for (int j = 0; j < 4; ++j) {
     if (j < n) {
@@ -327,6 +355,47 @@ int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, in
     ProfScope ps("small", s, 0.0, 8.0 * (double)total);
     hipLaunchKernelGGL(masked_copy_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, y, len,
                        div > 0 ? div : 1, (int64_t)C * T, T, total);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+// ---- folded batch: (N, C, T) <-> (C, N * P) with zero gaps (ops.h) -------------------------------------------------
+__global__ __launch_bounds__(256) void fold_kernel(const float* __restrict__ x, float* __restrict__ xf, const int64_t* __restrict__ len,
+                                                   int div, int N, int C, int T, int P, int64_t pitch) {
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;      // column of the folded row
+  const int c = blockIdx.y;
+  if (j >= pitch) return;
+  const int n = (int)(j / P), t = (int)(j - (int64_t)n * P);
+  float v = 0.f;
+  if (n < N && t < T && (!len || t < len[n / div])) v = x[((int64_t)n * C + c) * T + t];
+  xf[(int64_t)c * pitch + j] = v;
+}
+__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ xf, float* __restrict__ y, const int64_t* __restrict__ len,
+                                                     int div, int C, int T, int P, int64_t pitch, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int t = (int)(i % T);
+  const int64_t nc = i / T;
+  const int c = (int)(nc % C), n = (int)(nc / C);
+  y[i] = (!len || t < len[n / div]) ? xf[(int64_t)c * pitch + (int64_t)n * P + t] : 0.f;
+}
+
+int launch_fold(const float* x, float* xf, const int64_t* len, int div, int N, int C, int64_t T, int P, int64_t pitch, hipStream_t s) {
+  {
+    ProfScope ps("small", s, 0.0, 4.0 * (double)N * C * T + 4.0 * (double)C * pitch);
+    hipLaunchKernelGGL(fold_kernel, dim3((unsigned)((pitch + 255) / 256), (unsigned)C), dim3(256), 0, s, x, xf, len, div > 0 ? div : 1, N, C,
+                       (int)T, P, pitch);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+int launch_unfold(const float* xf, float* y, const int64_t* len, int div, int N, int C, int64_t T, int P, int64_t pitch, hipStream_t s) {
+  const int64_t total = (int64_t)N * C * T;
+  {
+    ProfScope ps("small", s, 0.0, 8.0 * (double)total);
+    hipLaunchKernelGGL(unfold_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xf, y, len, div > 0 ? div : 1, C, (int)T, P,
+                       pitch, total);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;

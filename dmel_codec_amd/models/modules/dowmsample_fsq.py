@@ -108,6 +108,9 @@ class DownsampleFiniteScalarQuantize(NativeModule):
         self.is_dmel, self.groups = is_dmel, n_groups
         self.levels = list(levels)
         self.fsq_prebound = bool(fsq_prebound)
+        #: strict encode (extension): project_in + bound in float64 inside encode() -- ids then depend only on the features, not on
+        #: a summation order (include/dmel_hip.h: dmel_quantizer_set_strict).  Plain attribute: set it before or after .to(device).
+        self.strict_encode = False
         self.input_dim = input_dim
         all_dims = (input_dim // n_groups,) + tuple(d // n_groups for d in downsample_dims)
         self.residual_fsq = _GroupedResidualFSQParams(dim=input_dim, groups=n_groups, levels=levels)
@@ -155,6 +158,7 @@ class DownsampleFiniteScalarQuantize(NativeModule):
         L = _lib.lib()
         with torch.cuda.device(z.device):
             h = self.native()
+            _lib.check(L.dmel_quantizer_set_strict(h, int(bool(self.strict_encode))), "quantizer_set_strict")
             ws = self._ws.get(L.dmel_quantizer_workspace_bytes(h, B, T), z.device)
             _lib.check(L.dmel_quantizer_encode(h, z.data_ptr(), ids.data_ptr(), _lib.ptr(pre), B, T, ws.data_ptr(),
                                                ws.numel(), _lib.stream_ptr()), "quantizer_encode")

@@ -179,6 +179,10 @@ int dmel_quantizer_create(dmel_quantizer** q, int input_dim /*= groups * dim_per
                           const int* levels, int n_levels, const int* downsample_factor, int n_factors,
                           int fsq_prebound);
 void dmel_quantizer_destroy(dmel_quantizer* q);
+/* Strict encode ("hard parts"): project_in (Linear C -> n_levels) and the tanh bound(s) of
+ * dmel_quantizer_encode are evaluated in float64 and rounded to fp32 once, so the value that is rounded to an id no longer depends
+ * on a summation order or a tanhf implementation.  Off by default (the fp32 path follows the reference's arithmetic). */
+int dmel_quantizer_set_strict(dmel_quantizer* q, int on);
 int dmel_quantizer_set_tensor(dmel_quantizer* q, const char* key, const float* data_host, const int64_t* shape, int ndim);
 int dmel_quantizer_finalize(dmel_quantizer* q);
 size_t dmel_quantizer_workspace_bytes(const dmel_quantizer* q, int B, int64_t T);

@@ -868,29 +868,35 @@ def test_quantizer_training_forward_backward(dev, levels, prebound, G, T, B):
         for m in q.modules():
             if hasattr(m, "gamma"):
                 m.gamma.normal_(0, 0.5)
-    sd64 = {k: v.double().requires_grad_() for k, v in cpu_sd(q).items()}
-    z = torch.randn(B * G, Cg, T)
-    gz = torch.randn(B, Cg * G, T)
-    z64 = z.double().requires_grad_()
-    zq64, ids64, lat64 = ref_cpu.quantizer_forward(sd64, "", z64, G, levels, (2, 2), prebound)
-    (zq64 * gz.double()).sum().backward()
     q = q.to(dev)
+    # A latent within rounding noise of a quantisation boundary may legitimately round the other way, which changes the whole
+    # straight-through gradient: the input is re-drawn (deterministically) until the float64 oracle keeps a 1e-4 margin to every
+    # boundary -- then ids must be EQUAL and the gradient check always runs (no skip).
+    gen = torch.Generator().manual_seed(1000 * T + G)
+    for attempt in range(20):
+        z = torch.randn(B * G, Cg, T, generator=gen)
+        sd64 = {k: v.double().requires_grad_() for k, v in cpu_sd(q).items()}
+        z64 = z.double().requires_grad_()
+        zq64, ids64, lat64 = ref_cpu.quantizer_forward(sd64, "", z64, G, levels, (2, 2), prebound)
+        _, pre64 = ref_cpu.quantizer_encode({k: v.detach() for k, v in sd64.items()}, "", z.double(), G, levels, (2, 2), prebound,
+                                            return_prequant=True)
+        if float((pre64 - torch.floor(pre64) - 0.5).abs().min()) > 1e-4:
+            break
+    else:
+        raise AssertionError("no input with a 1e-4 rounding margin in 20 draws")
+    gz = torch.randn(B, Cg * G, T, generator=gen)
+    (zq64 * gz.double()).sum().backward()
     zd = z.to(dev).requires_grad_()
     res = q(zd)
     assert res.z.shape == zq64.shape and res.codes.shape == ids64.shape and res.latents.shape == lat64.shape
     assert rel_err(res.latents, lat64) < 2e-5
-    # a latent within rounding noise of a quantisation boundary may legitimately round the other way: compare where ids agree
-    same = (res.codes.cpu() == ids64.cpu())
-    assert same.float().mean() > 0.98
-    if bool(same.all()):
-        assert rel_err(res.z, zq64) < 5e-5
-        (res.z * gz.to(dev)).sum().backward()
-        assert rel_err(zd.grad, z64.grad) < 1e-4
-        for k, p in q.named_parameters():
-            assert p.grad is not None, k
-            assert rel_err(p.grad, sd64[k].grad) < 2e-4, (k, rel_err(p.grad, sd64[k].grad))
-    else:
-        pytest.skip("a latent sits on a rounding boundary for this seed")
+    assert torch.equal(res.codes.cpu(), ids64.cpu().to(res.codes.dtype)), int((res.codes.cpu() != ids64.cpu()).sum())
+    assert rel_err(res.z, zq64) < 5e-5
+    (res.z * gz.to(dev)).sum().backward()
+    assert rel_err(zd.grad, z64.grad) < 1e-4
+    for k, p in q.named_parameters():
+        assert p.grad is not None, k
+        assert rel_err(p.grad, sd64[k].grad) < 2e-4, (k, rel_err(p.grad, sd64[k].grad))
     # optimiser-style in-place update: the handle is re-packed on the device, bit-identically to a rebuild through the host
     h_before = q._handle
     with torch.no_grad():
@@ -1095,9 +1101,10 @@ def test_full_training_step_matches_cpu_reference_loop(dev):
     for i, (audio, lens, noise) in enumerate(batches):
         logs = codec.training_step({"audios": audio.to(dev), "audio_lengths": lens.to(dev)}, i, noise=noise.to(dev))
         rd, rm, ra = ref_logs[i]
-        assert abs(logs["train/discriminator/loss"] - rd) < 2e-4 * abs(rd), (i, logs, ref_logs[i])
-        assert abs(logs["train/generator/loss_mel"] - rm) < 2e-4 * abs(rm), (i, logs, ref_logs[i])
-        assert abs(logs["train/generator/loss_adv"] - ra) < 2e-4 * abs(ra), (i, logs, ref_logs[i])
+        # north_star: losses within 1e-4 relative in fp32
+        assert abs(logs["train/discriminator/loss"] - rd) < 1e-4 * abs(rd), (i, logs, ref_logs[i])
+        assert abs(logs["train/generator/loss_mel"] - rm) < 1e-4 * abs(rm), (i, logs, ref_logs[i])
+        assert abs(logs["train/generator/loss_adv"] - ra) < 1e-4 * abs(ra), (i, logs, ref_logs[i])
     after = cpu_sd(codec)
     # AdamW normalises every element's step to ~lr, so elements whose gradient is near zero turn rounding noise into O(lr) differences:
     # the bar on parameters is a fraction of the accumulated step (2 x lr = 4e-3 absolute), not the 1e-4 of a forward pass

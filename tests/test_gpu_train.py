@@ -68,7 +68,7 @@ def test_wavenet_backward_hands_over_gradients_block_by_block(dev, cfg):
     assert all(n == per_block for _, n in spans[1:L + 1])
     for k, p in trained:
         assert p.grad is not None and base <= p.grad.data_ptr() < base + total, k   # views of the flat buffer
-        assert torch.equal(p.grad, plain[k]), k
+        assert torch.allclose(p.grad, plain[k], rtol=1e-5, atol=1e-5 * float(plain[k].abs().max())), k   # fp32 atomics: run-to-run rounding
     assert all(p.grad is None for k, p in m.named_parameters() if "diffusion_projection" in k)
     # gradients already present: nothing is streamed, the whole buffer (old + new) goes out once, after the add
     rec2 = _Recorder()
@@ -77,7 +77,7 @@ def test_wavenet_backward_hands_over_gradients_block_by_block(dev, cfg):
     m._grad_sink = None
     assert len(rec2.regions) == 1 and rec2.regions[0][1] * 4 == total
     for k, p in trained:
-        assert torch.allclose(p.grad, 2 * plain[k], rtol=1e-6, atol=1e-6), k
+        assert torch.allclose(p.grad, 2 * plain[k], rtol=1e-5, atol=2e-5 * float(plain[k].abs().max())), k
 
 
 def test_backward_after_optimizer_step_is_refused(dev):

@@ -200,3 +200,39 @@ def test_discriminator_oracle_matches_reference(golden):
             p = sd[k[5:]]
             r = torch.randn(p.shape, generator=torch.Generator().manual_seed(p.numel()))
             assert abs(float((p.grad * r).sum()) - float(ref)) < 1e-3 * max(1.0, abs(float(ref))), k
+
+
+def test_mel_basis_matches_an_independent_slaney_implementation():
+    """librosa (the reference's source of the mel basis, utils/spectrogram.py:45-52) is absent, and the reference holds no fixture
+    for it; `transformers.audio_utils.mel_filter_bank(norm="slaney", mel_scale="slaney")` is an independent implementation of the
+    same published definition (it is what HF feature extractors use in place of librosa.filters.mel) and IS installed here: the
+    oracle's restatement and the product's C++ restatement (tests/test_cpu_abi.py::test_mel_basis_matches_oracle holds those two
+    together) agree with it to float32 rounding on every configuration of the codec."""
+    import pytest
+    audio_utils = pytest.importorskip("transformers.audio_utils")
+    for sr, n_fft, n_mels, fmax in [(24000, 1024, 100, 12000.0), (16000, 1024, 80, None), (24000, 1024, 80, None), (44100, 2048, 128, None)]:
+        ours = np.asarray(ref_cpu.slaney_mel_basis(sr, n_fft, n_mels, 0.0, fmax))
+        theirs = audio_utils.mel_filter_bank(num_frequency_bins=n_fft // 2 + 1, num_mel_filters=n_mels, min_frequency=0.0,
+                                             max_frequency=fmax if fmax is not None else sr / 2, sampling_rate=sr, norm="slaney",
+                                             mel_scale="slaney").T
+        assert ours.shape == theirs.shape == (n_mels, n_fft // 2 + 1)
+        assert np.abs(ours - theirs).max() < 1e-8 and np.abs(ours - theirs).max() / np.abs(theirs).max() < 2e-7, (sr, n_mels)
+
+
+def test_strict_fsq_restatement():
+    """Strict encode (project_in + bound in float64, rounded once): equals the fp32 restatement up to fp32 rounding noise, is
+    invariant to the summation order of the Linear (a permutation of the input channels changes nothing, while the fp32 path moves
+    in the last bits), and yields the same ids away from rounding boundaries."""
+    g = torch.Generator().manual_seed(3)
+    levels = [7, 5, 5]
+    sd = {"project_in.weight": torch.randn(3, 70, generator=g) * 0.4, "project_in.bias": torch.randn(3, generator=g) * 0.1}
+    x = torch.randn(2000, 70, generator=g)
+    for prebound in (True, False):
+        a = ref_cpu.fsq_prequant(sd, "", x, levels, prebound)
+        s = ref_cpu.fsq_prequant(sd, "", x, levels, prebound, strict=True)
+        assert s.dtype == torch.float32 and (a - s).abs().max() < 5e-5
+        perm = torch.randperm(70, generator=g)
+        sd_p = {"project_in.weight": sd["project_in.weight"][:, perm], "project_in.bias": sd["project_in.bias"]}
+        assert torch.equal(ref_cpu.fsq_prequant(sd_p, "", x[:, perm], levels, prebound, strict=True), s)
+        far = ((a - a.floor() - 0.5).abs() > 1e-4).all(-1)
+        assert torch.equal(ref_cpu.fsq_indices_from_prequant(a, levels)[far], ref_cpu.fsq_indices_from_prequant(s, levels)[far])
