@@ -49,8 +49,8 @@ PROTOTYPES = {
     "dmel_stft_plan_mel_basis": (C.c_int, [vp, vp]),
     "dmel_stft_num_frames": (C.c_int64, [vp, C.c_int64]),
     "dmel_stft_logmel_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int64, vp]),
-    "dmel_aa_snake_f32": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
-    "dmel_aa_snake_backward_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    "dmel_aa_snake_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
+    "dmel_aa_snake_backward_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_discriminator_create": (C.c_int, [C.POINTER(vp)]),
     "dmel_discriminator_destroy": (None, [vp]),
     "dmel_discriminator_set_tensor": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]),
@@ -88,6 +88,7 @@ PROTOTYPES = {
     "dmel_wavenet_forward_train": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_wavenet_backward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_wavenet_backward_hooked": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp, GRAD_READY_FN, vp]),
+    "dmel_wavenet_stream_step": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int64, i64p, i64p, vp]),
     "dmel_wavenet_set_tensor": (C.c_int, [vp, C.c_char_p, vp, i64p, C.c_int]),
     "dmel_wavenet_finalize": (C.c_int, [vp]),
     "dmel_wavenet_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
@@ -99,6 +100,7 @@ PROTOTYPES = {
     "dmel_quantizer_finalize": (C.c_int, [vp]),
     "dmel_quantizer_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_quantizer_encode": (C.c_int, [vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
+    "dmel_quantizer_encode_ex": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_quantizer_decode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_quantizer_enable_training": (C.c_int, [vp, C.c_int]),
     "dmel_quantizer_refresh": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), vp]),

@@ -52,9 +52,10 @@ __device__ __forceinline__ float sin_sq(float x) {
 // 32-bit indices, and tiles that do not touch a sequence edge (block-uniform test) skip every clamp and select.
 // (A v_pk_fma_f32 version of this kernel measured 0.6x: packed fp32 issues at half rate on gfx950.  Four consecutive samples
 // per thread with ds_read_b128 windows -- 8 LDS reads instead of 56 per four outputs -- measured 0.84x: 2.26 vs 2.74 TB/s.)
+// tu: the up-sampling taps times 2 (the x2 gain of UpSample1d, resample.py:37; exact in fp32), td: the low-pass taps of DownSample1d
 template <bool EDGE>
-__device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, float* __restrict__ yr, const Taps12& tp, float a,
-                                              float inv_b, int t0, int len, int T, float* xs, float2* vs, int tid) {
+__device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, float* __restrict__ yr, const Taps12& tu, const Taps12& td,
+                                              float a, float inv_b, int t0, int len, int T, float* xs, float2* vs, int tid) {
   for (int i = tid; i < len + 12; i += 256) {
     int s = t0 - 6 + i;
     if (EDGE) s = min(max(s, 0), T - 1);
@@ -68,11 +69,9 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
     float ue = 0.f, uo = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      ue = fmaf(tp.f[2 * j + 1], xp[2 - j], ue);
-      uo = fmaf(tp.f[2 * j], xp[3 - j], uo);
+      ue = fmaf(tu.f[2 * j + 1], xp[2 - j], ue);
+      uo = fmaf(tu.f[2 * j], xp[3 - j], uo);
     }
-    ue *= 2.f;
-    uo *= 2.f;
     float ve = fmaf(inv_b, sin_sq(ue * a), ue);
     float vo = fmaf(inv_b, sin_sq(uo * a), uo);
     if (EDGE) {
@@ -85,25 +84,25 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
   for (int o = tid; o < len; o += 256) {
     const float2 p0 = vs[o], p1 = vs[o + 1], p2 = vs[o + 2], p3 = vs[o + 3], p4 = vs[o + 4], p5 = vs[o + 5],
                  p6 = vs[o + 6];
-    float acc = tp.f[0] * p0.y;
-    acc = fmaf(tp.f[1], p1.x, acc);
-    acc = fmaf(tp.f[2], p1.y, acc);
-    acc = fmaf(tp.f[3], p2.x, acc);
-    acc = fmaf(tp.f[4], p2.y, acc);
-    acc = fmaf(tp.f[5], p3.x, acc);
-    acc = fmaf(tp.f[6], p3.y, acc);
-    acc = fmaf(tp.f[7], p4.x, acc);
-    acc = fmaf(tp.f[8], p4.y, acc);
-    acc = fmaf(tp.f[9], p5.x, acc);
-    acc = fmaf(tp.f[10], p5.y, acc);
-    acc = fmaf(tp.f[11], p6.x, acc);
+    float acc = td.f[0] * p0.y;
+    acc = fmaf(td.f[1], p1.x, acc);
+    acc = fmaf(td.f[2], p1.y, acc);
+    acc = fmaf(td.f[3], p2.x, acc);
+    acc = fmaf(td.f[4], p2.y, acc);
+    acc = fmaf(td.f[5], p3.x, acc);
+    acc = fmaf(td.f[6], p3.y, acc);
+    acc = fmaf(td.f[7], p4.x, acc);
+    acc = fmaf(td.f[8], p4.y, acc);
+    acc = fmaf(td.f[9], p5.x, acc);
+    acc = fmaf(td.f[10], p5.y, acc);
+    acc = fmaf(td.f[11], p6.x, acc);
     yr[t0 + o] = acc;
   }
 }
 
 __global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                           const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                          Taps12 tp, int logscale, int C, int T) {
+                                                          Taps12 tu, Taps12 td, int logscale, int C, int T) {
   __shared__ float xs[kSnakeTile + 12];
   __shared__ float2 vs[kSnakeTile + 6];
   const int c = blockIdx.y, b = blockIdx.z;
@@ -117,8 +116,8 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__
     a = expf(a);
   }
   const float inv_b = 1.0f / (bt + 1e-9f);
-  if (t0 >= 6 && t0 + len + 6 <= T) aa_snake_tile<false>(xr, yr, tp, a, inv_b, t0, len, T, xs, vs, threadIdx.x);
-  else aa_snake_tile<true>(xr, yr, tp, a, inv_b, t0, len, T, xs, vs, threadIdx.x);
+  if (t0 >= 6 && t0 + len + 6 <= T) aa_snake_tile<false>(xr, yr, tu, td, a, inv_b, t0, len, T, xs, vs, threadIdx.x);
+  else aa_snake_tile<true>(xr, yr, tu, td, a, inv_b, t0, len, T, xs, vs, threadIdx.x);
 }
 
 // ---- backward ------------------------------------------------------------------------------------------------------
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(256) void aa_snake_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void aa_snake_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ dx, const float* __restrict__ alpha,
                                                             const float* __restrict__ beta, float* __restrict__ dalpha,
-                                                            float* __restrict__ dbeta, Taps12 tp, int logscale, int C, int T) {
+                                                            float* __restrict__ dbeta, Taps12 tu, Taps12 td, int logscale, int C, int T) {
   __shared__ float xs[kSnakeTile + 12];
   __shared__ float dys[kSnakeTile + 12];
   __shared__ float dvs[2 * (kSnakeTile + 6)];
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(256) void aa_snake_bwd_kernel(const float* __restri
     for (int k = 0; k < 12; ++k) {
       const int vi = min(max(2 * t + k - 5, 0), 2 * T - 1);
       const int p = (vi >> 1) - (t0 - 3);
-      if (p >= 0 && p < len + 6) atomicAdd(&dvs[2 * p + (vi & 1)], tp.f[k] * g);
+      if (p >= 0 && p < len + 6) atomicAdd(&dvs[2 * p + (vi & 1)], td.f[k] * g);
     }
   }
   __syncthreads();
@@ -182,11 +181,9 @@ __global__ __launch_bounds__(256) void aa_snake_bwd_kernel(const float* __restri
     float ue = 0.f, uo = 0.f;
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
-      ue = fmaf(tp.f[2 * j + 1], xp[2 - j], ue);
-      uo = fmaf(tp.f[2 * j], xp[3 - j], uo);
+      ue = fmaf(tu.f[2 * j + 1], xp[2 - j], ue);
+      uo = fmaf(tu.f[2 * j], xp[3 - j], uo);
     }
-    ue *= 2.f;
-    uo *= 2.f;
     const float dve = dvs[2 * p], dvo = dvs[2 * p + 1];
     const float s2e = sinf(2.f * a * ue), s2o = sinf(2.f * a * uo);
     const float due = dve * fmaf(a * inv_b, s2e, 1.f), duo = dvo * fmaf(a * inv_b, s2o, 1.f);
@@ -197,8 +194,8 @@ __global__ __launch_bounds__(256) void aa_snake_bwd_kernel(const float* __restri
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
       const int se = min(max(m + 2 - j, 0), T - 1) - t0, so = min(max(m + 3 - j, 0), T - 1) - t0;
-      if (se >= 0 && se < len) atomicAdd(&dxs[se], 2.f * tp.f[2 * j + 1] * due);
-      if (so >= 0 && so < len) atomicAdd(&dxs[so], 2.f * tp.f[2 * j] * duo);
+      if (se >= 0 && se < len) atomicAdd(&dxs[se], tu.f[2 * j + 1] * due);
+      if (so >= 0 && so < len) atomicAdd(&dxs[so], tu.f[2 * j] * duo);
     }
   }
 #pragma unroll
@@ -223,33 +220,33 @@ __global__ __launch_bounds__(256) void aa_snake_bwd_kernel(const float* __restri
 }
 
 int launch_aa_snake_bwd(const float* x, const float* dy, float* dx, const float* alpha, const float* beta, float* dalpha, float* dbeta,
-                        const float* taps_host, int logscale, int B, int C, int64_t T, hipStream_t s) {
-  DMEL_CHECK_ARG(x && dy && dx && alpha && dalpha && taps_host, "aa_snake_backward: NULL argument");
+                        const float* up_taps_host, const float* down_taps_host, int logscale, int B, int C, int64_t T, hipStream_t s) {
+  DMEL_CHECK_ARG(x && dy && dx && alpha && dalpha && up_taps_host && down_taps_host, "aa_snake_backward: NULL argument");
   DMEL_CHECK_ARG((beta != nullptr) == (dbeta != nullptr), "aa_snake_backward: dbeta must be given exactly when beta is");
   DMEL_CHECK_ARG(B > 0 && C > 0 && T > 0 && B <= 65535 && C <= 65535 && T < ((int64_t)1 << 29), "aa_snake_backward: bad shape");
-  Taps12 tp;
-  for (int i = 0; i < 12; ++i) tp.f[i] = taps_host[i];
+  Taps12 tu, td;
+  for (int i = 0; i < 12; ++i) { tu.f[i] = 2.f * up_taps_host[i]; td.f[i] = down_taps_host[i]; }
   DMEL_HIP(hipMemsetAsync(dalpha, 0, (size_t)C * sizeof(float), s));
   if (dbeta) DMEL_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * sizeof(float), s));
   dim3 grid((unsigned)((T + kSnakeTile - 1) / kSnakeTile), (unsigned)C, (unsigned)B);
   {
     ProfScope ps("aa_snake_bwd", s, 0.0, 12.0 * (double)B * C * (double)T);
-    hipLaunchKernelGGL(aa_snake_bwd_kernel, grid, dim3(256), 0, s, x, dy, dx, alpha, beta, dalpha, dbeta, tp, logscale, C, (int)T);
+    hipLaunchKernelGGL(aa_snake_bwd_kernel, grid, dim3(256), 0, s, x, dy, dx, alpha, beta, dalpha, dbeta, tu, td, logscale, C, (int)T);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
 }
 
-int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* taps_host, int logscale,
-                    int B, int C, int64_t T, hipStream_t s) {
-  DMEL_CHECK_ARG(x && y && alpha && taps_host, "aa_snake: NULL argument");
+int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* up_taps_host,
+                    const float* down_taps_host, int logscale, int B, int C, int64_t T, hipStream_t s) {
+  DMEL_CHECK_ARG(x && y && alpha && up_taps_host && down_taps_host, "aa_snake: NULL argument");
   DMEL_CHECK_ARG(B > 0 && C > 0 && T > 0 && B <= 65535 && C <= 65535 && T < ((int64_t)1 << 30), "aa_snake: bad shape");
-  Taps12 tp;
-  for (int i = 0; i < 12; ++i) tp.f[i] = taps_host[i];
+  Taps12 tu, td;
+  for (int i = 0; i < 12; ++i) { tu.f[i] = 2.f * up_taps_host[i]; td.f[i] = down_taps_host[i]; }
   dim3 grid((unsigned)((T + kSnakeTile - 1) / kSnakeTile), (unsigned)C, (unsigned)B);
   {
     ProfScope ps("aa_snake", s, 0.0, 8.0 * (double)B * C * (double)T);
-    hipLaunchKernelGGL(aa_snake_kernel, grid, dim3(256), 0, s, x, y, alpha, beta, tp, logscale, C, (int)T);
+    hipLaunchKernelGGL(aa_snake_kernel, grid, dim3(256), 0, s, x, y, alpha, beta, tu, td, logscale, C, (int)T);
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
@@ -258,12 +255,13 @@ int launch_aa_snake(const float* x, float* y, const float* alpha, const float* b
 }  // namespace dmel
 
 extern "C" int dmel_aa_snake_backward_f32(const float* x, const float* dy, float* dx, const float* alpha, const float* beta,
-                                          float* dalpha, float* dbeta, const float* filter12_host, int logscale, int B, int C, int64_t T,
-                                          void* stream) {
-  return dmel::launch_aa_snake_bwd(x, dy, dx, alpha, beta, dalpha, dbeta, filter12_host, logscale, B, C, T, (hipStream_t)stream);
+                                          float* dalpha, float* dbeta, const float* up_filter12_host, const float* down_filter12_host,
+                                          int logscale, int B, int C, int64_t T, void* stream) {
+  return dmel::launch_aa_snake_bwd(x, dy, dx, alpha, beta, dalpha, dbeta, up_filter12_host, down_filter12_host, logscale, B, C, T,
+                                   (hipStream_t)stream);
 }
 
-extern "C" int dmel_aa_snake_f32(const float* x, float* y, const float* alpha, const float* beta, const float* filter12_host,
-                                 int logscale, int B, int C, int64_t T, void* stream) {
-  return dmel::launch_aa_snake(x, y, alpha, beta, filter12_host, logscale, B, C, T, (hipStream_t)stream);
+extern "C" int dmel_aa_snake_f32(const float* x, float* y, const float* alpha, const float* beta, const float* up_filter12_host,
+                                 const float* down_filter12_host, int logscale, int B, int C, int64_t T, void* stream) {
+  return dmel::launch_aa_snake(x, y, alpha, beta, up_filter12_host, down_filter12_host, logscale, B, C, T, (hipStream_t)stream);
 }

@@ -67,7 +67,7 @@ ProfScope::~ProfScope() {
 using namespace dmel;
 
 extern "C" const char* dmel_last_error(void) { return g_err.c_str(); }
-extern "C" int dmel_abi_version(void) { return 1; }
+extern "C" int dmel_abi_version(void) { return 2; }   // 2: dmel_aa_snake_* take separate up / down filters; hooked backward; strict encode
 
 extern "C" int dmel_prof_enable(int on) {
   ProfState& p = prof();

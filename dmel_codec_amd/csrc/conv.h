@@ -65,6 +65,7 @@ struct SegRun {
   int64_t bstride = 0, cstride = 0, Tin = 0;
   const int64_t* in_len = nullptr;
   float in_scale = 1.f;
+  int64_t tshift = 0;      // output column q reads input column (q + tshift) * tstride + ...: a launch over a sub-range of a longer row
 };
 
 struct ConvRun {

@@ -915,7 +915,7 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     o.x = r.seg[s].x; o.bstride = r.seg[s].bstride; o.cstride = r.seg[s].cstride; o.Tin = r.seg[s].Tin;
     o.in_len = r.seg[s].in_len; o.in_scale = r.seg[s].in_scale;
     o.Cin = sd.Cin; o.nchunk = (sd.Cin + kCK - 1) / kCK; o.taps = sd.taps; o.dil = sd.dil;
-    o.pad_left = sd.pad_left; o.tstride = sd.tstride; o.toff = sd.toff;
+    o.pad_left = sd.pad_left; o.tstride = sd.tstride; o.toff = sd.toff + (int)(r.seg[s].tshift * sd.tstride);
     max_halo = std::max(max_halo, (sd.taps - 1) * sd.dil);
     // the staging code addresses one batch item with unsigned 32-bit BYTE offsets
     DMEL_CHECK_ARG((int64_t)sd.Cin * o.cstride < ((int64_t)1 << 30) && o.Tin * sd.tstride < ((int64_t)1 << 30),

@@ -477,6 +477,71 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
   return DMEL_OK;
 }
 
+// ---- incremental forward (include/dmel_hip.h: dmel_wavenet_stream_step) ----------------------------------------------------
+extern "C" int dmel_wavenet_stream_step(const dmel_wavenet* m, float* hist, float* skip, const float* cond, float* y, float* scratch,
+                                        int N, int64_t cap, const int64_t* prev, const int64_t* next, void* stream) {
+  DMEL_CHECK_ARG(m && hist && skip && y && scratch && prev && next, "wavenet_stream_step: NULL argument");
+  if (!m->ready) { set_error("wavenet_stream_step: handle not finalized"); return DMEL_EMISSING; }
+  DMEL_CHECK_ARG((m->Ccond != 0) == (cond != nullptr), "wavenet_stream_step: condition tensor does not match the configuration");
+  if (m->has_in) { set_error("wavenet_stream_step: models with an input projection are not supported (the decoder has none)"); return DMEL_EUNSUPPORTED; }
+  DMEL_CHECK_ARG(N > 0 && cap > 0, "wavenet_stream_step: bad shape");
+  const int C = m->C, L = m->L;
+  const bool final_step = next[L] == next[0];
+  for (int l = 0; l <= L; ++l) {
+    DMEL_CHECK_ARG(prev[l] >= 0 && prev[l] <= next[l] && next[l] <= cap, "wavenet_stream_step: level %d: need 0 <= prev <= next <= cap", l);
+    if (l > 0) {
+      const int dil = m->cycle ? 1 << ((l - 1) % m->cycle) : 1;
+      DMEL_CHECK_ARG(final_step ? next[l] == next[0] : (next[l] == prev[l] || next[l] + dil <= next[l - 1]),
+                     "wavenet_stream_step: level %d runs ahead of its input (next %lld, input next %lld, dilation %d)", l,
+                     (long long)next[l], (long long)next[l - 1], dil);
+      DMEL_CHECK_ARG(prev[l] <= prev[l - 1], "wavenet_stream_step: level %d is ahead of level %d", l, l - 1);
+    }
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t bs = (int64_t)C * cap, lvl = (int64_t)N * bs;
+  float* zb = scratch;                        // gate output of the block being computed, (N, C, cap)
+  auto sub = [&](const float* x, int Cin, int64_t valid, int64_t p, float* out, int Cout, int64_t cols) {
+    ConvRun r;
+    r.seg[0].x = x; r.seg[0].bstride = (int64_t)Cin * cap; r.seg[0].cstride = cap; r.seg[0].Tin = valid; r.seg[0].tshift = p;
+    r.B = N; r.Tcols = cols; r.y = out + p; r.y_bs = (int64_t)Cout * cap; r.y_cs = cap; r.Tout = cols;
+    r.precision = m->precision;
+    return r;
+  };
+  for (int i = 0; i < L; ++i) {  // wavenet.py:116-135 on the new columns of block i + 1
+    const int64_t p = prev[i + 1], cols = next[i + 1] - p;
+    if (cols <= 0) continue;
+    const float* xin = hist + (int64_t)i * lvl;
+    float* xout = hist + (int64_t)(i + 1) * lvl;
+    ConvRun g = sub(xin, C, next[i], p, zb, C, cols);
+    if (m->Ccond) {
+      g.seg[1].x = cond; g.seg[1].bstride = (int64_t)m->Ccond * cap; g.seg[1].cstride = cap; g.seg[1].Tin = next[0]; g.seg[1].tshift = p;
+    }
+    DMEL_TRY(launch_conv(m->gate[i], g, st));
+    // the residual update is in place in the whole-sequence kernel ((x + r) / sqrt2 over x): here block i's input must survive as
+    // history, so its new columns are first copied into block i + 1's rows and updated there
+    DMEL_HIP(hipMemcpy2DAsync(xout + p, (size_t)cap * sizeof(float), xin + p, (size_t)cap * sizeof(float), (size_t)cols * sizeof(float),
+                              (size_t)N * C, hipMemcpyDeviceToDevice, st));
+    ConvRun r = sub(zb, C, next[i + 1], p, xout, C, cols);
+    r.skip = skip + p; r.skip_first = (i == 0);
+    DMEL_TRY(launch_conv(m->resskip[i], r, st));
+  }
+  {  // wavenet.py:218-223 on the columns whose skip sum is complete
+    const int64_t p = prev[L], cols = next[L] - p;
+    if (cols > 0) {
+      float* tb = scratch + (int64_t)N * bs;    // second half of the scratch
+      ConvRun r = sub(skip, C, next[L], p, m->has_out ? tb : y, C, cols);
+      r.seg[0].in_scale = (float)(1.0 / std::sqrt((double)m->L));
+      if (m->has_out) r.act = ACT_SILU;
+      DMEL_TRY(launch_conv(m->skip_proj, r, st));
+      if (m->has_out) {
+        ConvRun o = sub(tb, C, next[L], p, y, m->Cout, cols);
+        DMEL_TRY(launch_conv(m->out_proj, o, st));
+      }
+    }
+  }
+  return DMEL_OK;
+}
+
 // ---- WaveNet training path --------------------------------------------------------------------------------------
 // forward_train computes exactly wavenet.py:204-225 but unfused, keeping what backward needs (every block's input, gate
 // pre-activation and gated output; the SiLU inputs); backward is reverse-mode differentiation of that graph -- what
@@ -1116,6 +1181,11 @@ extern "C" size_t dmel_quantizer_workspace_bytes(const dmel_quantizer* q, int B,
 
 extern "C" int dmel_quantizer_encode(const dmel_quantizer* q, const float* z, int32_t* ids, float* prequant, int B, int64_t T,
                                      void* workspace, size_t workspace_bytes, void* stream) {
+  return dmel_quantizer_encode_ex(q, z, ids, prequant, nullptr, B, T, workspace, workspace_bytes, stream);
+}
+
+extern "C" int dmel_quantizer_encode_ex(const dmel_quantizer* q, const float* z, int32_t* ids, float* prequant, float* latents, int B,
+                                        int64_t T, void* workspace, size_t workspace_bytes, void* stream) {
   DMEL_CHECK_ARG(q && z && ids && workspace, "quantizer_encode: NULL argument");
   if (!q->ready) { set_error("quantizer_encode: handle not finalized"); return DMEL_EMISSING; }
   int64_t Tq = T;
@@ -1140,6 +1210,7 @@ extern "C" int dmel_quantizer_encode(const dmel_quantizer* q, const float* z, in
     cur = o;
     Tc = Tn;
   }
+  if (latents) DMEL_HIP(hipMemcpyAsync(latents, cur, (size_t)N * C * Tc * sizeof(float), hipMemcpyDeviceToDevice, st));
   // "(b g) f t -> b (g f) t" is a view; FSQ per group (dowmsample_fsq.py:127-132)
   return launch_fsq_encode(cur, q->w_in.as<float>(), q->b_in.as<float>(), ids, prequant, q->fk, B, q->G, C, Tc, st);
 }
@@ -1988,7 +2059,7 @@ struct dmel_bigvgan {
   std::vector<UpStage> ups;
   std::vector<AmpBlock> blocks;
   SnakeP act_post;
-  float taps[12];
+  float taps_up[12], taps_dn[12];   // UpSample1d.filter / DownSample1d.lowpass.filter (the reference registers the same 12 taps for both)
   int64_t total_up = 1;
   // The AMP blocks of a stage are independent until their outputs are averaged: they run on the caller's stream plus
   // up to two library-owned side streams, forked and joined with events around every stage, so the VALU-bound
@@ -2042,7 +2113,8 @@ extern "C" int dmel_bigvgan_create(dmel_bigvgan** out, const dmel_bigvgan_config
   // "*.filter" buffer found in the state dict.
   static const float kTaps[12] = {0.0020289647f, 0.0093894657f, -0.0255434588f, -0.0576573834f, 0.1285725832f, 0.4432097971f,
                                   0.4432097971f, 0.1285725832f, -0.0576573834f, -0.0255434588f, 0.0093894657f, 0.0020289647f};
-  std::memcpy(m->taps, kTaps, sizeof(kTaps));
+  std::memcpy(m->taps_up, kTaps, sizeof(kTaps));
+  std::memcpy(m->taps_dn, kTaps, sizeof(kTaps));
   *out = m;
   return DMEL_OK;
 }
@@ -2090,16 +2162,21 @@ extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
   DMEL_CHECK_ARG(m, "NULL handle");
   const dmel_bigvgan_config& c = m->cfg;
   const bool snake = c.activation_snake != 0;
-  // anti-alias taps: every Activation1d registers the same two buffers; accept them if present and identical
-  bool have = false;
+  // anti-alias taps: every Activation1d registers two buffers ("...upsample.filter", "...downsample.lowpass.filter"); all up filters
+  // must agree with each other and all down filters with each other (one launch-constant pair per model); up and down may differ
+  bool have_up = false, have_dn = false;
   for (auto& kv : m->ts.t) {
     const std::string& k = kv.first;
     const bool is_f = k.size() > 7 && k.compare(k.size() - 7, 7, ".filter") == 0;
     if (!is_f) continue;
     if (kv.second.numel() != 12) { set_error("bigvgan: filter '%s' is not 12 taps", k.c_str()); return DMEL_EUNSUPPORTED; }
-    if (!have) { std::memcpy(m->taps, kv.second.v.data(), sizeof(m->taps)); have = true; }
-    else if (std::memcmp(m->taps, kv.second.v.data(), sizeof(m->taps)) != 0) {
-      set_error("bigvgan: anti-alias filter '%s' differs from the others (per-activation filters unsupported)", k.c_str());
+    const bool is_dn = k.find("downsample") != std::string::npos;
+    float* dst = is_dn ? m->taps_dn : m->taps_up;
+    bool& have = is_dn ? have_dn : have_up;
+    if (!have) { std::memcpy(dst, kv.second.v.data(), 12 * sizeof(float)); have = true; }
+    else if (std::memcmp(dst, kv.second.v.data(), 12 * sizeof(float)) != 0) {
+      set_error("bigvgan: anti-alias filter '%s' differs from the other %s filters (per-activation filters unsupported)", k.c_str(),
+                is_dn ? "down-sampling" : "up-sampling");
       return DMEL_EUNSUPPORTED;
     }
   }
@@ -2251,12 +2328,12 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
         // stagger the branches by one kernel: started together they run snake|snake|snake then conv|conv|conv in lockstep
         // and the VALU-bound activations never meet the matrix-pipe-bound convolutions on a CU
         if (l == 0 && multi && stagger && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_stag[j - 1], 0));
-        DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps, logscale, B, ch, Tc, sj));
+        DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
         if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
         ConvRun r1 = run_1seg(uj, ch, Tc, vj, ch, Tc, B);
         r1.precision = m->precision;
     DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
-        DMEL_TRY(launch_aa_snake(vj, uj, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps, logscale, B, ch, Tc, sj));
+        DMEL_TRY(launch_aa_snake(vj, uj, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
         ConvRun r2 = run_1seg(uj, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
         r2.res = xin; r2.res_bs = bs; r2.res_cs = Tc;
         if (l == 2) {
@@ -2280,7 +2357,7 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
     std::swap(x, xs);
   }
   // activation_post, conv_post, tanh | clamp (bigvgan.py:385-391)
-  DMEL_TRY(launch_aa_snake(x, ua, m->act_post.alpha.as<float>(), m->act_post.beta.as<float>(), m->taps, logscale, B, ch, Tc, st));
+  DMEL_TRY(launch_aa_snake(x, ua, m->act_post.alpha.as<float>(), m->act_post.beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, st));
   return launch_conv_post(ua, audio, m->post_w.as<float>(), m->post_bias, c.use_tanh_at_final ? ACT_TANH : ACT_CLAMP1, B, ch, 7,
                           Tc, st);
 }

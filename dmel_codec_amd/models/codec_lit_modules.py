@@ -7,6 +7,7 @@ dmel_codec/models/codec_lit_modules.py (reference): same ctor kwargs, attribute 
 Every tensor op of the path is a native HIP launch; torch only owns the memory and the stream."""
 from __future__ import annotations
 
+import ctypes as C
 import math
 from pathlib import Path
 from typing import Callable, Optional
@@ -346,13 +347,52 @@ class VQGAN(nn.Module):
         return gen_mel
 
     # ------------------------------------------------------------------------------ streaming decode (extension)
+    def streaming_decoder(self, batch: int = 1, feature_lengths: Optional[torch.Tensor] = None, return_audios: bool = True):
+        """Incremental decode with state carry (the reference decodes once, after the LM has finished,
+        lm_lit_modules.py:467-471): feed token chunks as they arrive with .push(ids (B, G, n)), get audio back as soon as its right
+        context exists; .finish() flushes.  See StreamingDecoder."""
+        return StreamingDecoder(self, batch, feature_lengths, return_audios)
+
+    @torch.no_grad()
+    def decode_stream(self, indices, feature_lengths=None, chunk_tokens: int = 64, noise: Optional[torch.Tensor] = None,
+                      return_audios: bool = True):
+        """Generator: decode() fed `chunk_tokens` tokens at a time (indices: a (B, G, T4) tensor, or any iterable of (B, G, n) chunks),
+        yielding (audio | None, gen_mel) pieces whose concatenation is BIT-identical to decode() on the whole sequence.  The decoder
+        WaveNet keeps the output history of every block and only ever computes new columns (dmel_wavenet_stream_step: total work 1.0x);
+        the quantiser and the vocoder -- receptive fields of 3 and ~20 frames -- run on the new frames plus that context and are
+        cropped.  A piece is emitted once its right context (WaveNet 75 + vocoder ~20 frames) has arrived.
+        noise: (B, C, 4 T4) for reproducible runs (tensor input only), else drawn per chunk like decode() draws it."""
+        if torch.is_tensor(indices):
+            T4 = indices.shape[2]
+            chunks = (indices[:, :, a:a + chunk_tokens] for a in range(0, T4, chunk_tokens))
+            batch = indices.shape[0]
+        else:
+            chunks = iter(indices)
+            first = next(chunks)
+            batch = first.shape[0]
+            import itertools
+            chunks = itertools.chain([first], chunks)
+        dec = self.streaming_decoder(batch, feature_lengths, return_audios)
+        factor = math.prod(self.quantizer.downsample_factor)
+        pos = 0
+        for ids in chunks:
+            n = ids.shape[2]
+            nz = noise[:, :, pos * factor:(pos + n) * factor] if noise is not None else None
+            pos += n
+            out = dec.push(ids, noise=nz)
+            if out[1].shape[-1]:
+                yield out
+        out = dec.finish()
+        if out[1].shape[-1]:
+            yield out
+
     #: mel frames of context the decode path needs on each side of a chunk for its interior to be exact:
     #: conditional WaveNet 20 layers x dilations (1,2,4,8) = 75, BigVGAN-base ~19 (conv_pre 3 + AMP/snake halos of the
     #: four stages), quantiser ConvNeXt stacks ~3.  Chunks carry a 32-token (128-frame) halo.
     STREAM_HALO_TOKENS = 32
 
     @torch.no_grad()
-    def decode_stream(self, indices, feature_lengths, chunk_tokens: int = 64, halo_tokens: Optional[int] = None,
+    def _decode_windows(self, indices, feature_lengths, chunk_tokens: int = 64, halo_tokens: Optional[int] = None,
                       noise: Optional[torch.Tensor] = None, return_audios: bool = True):
         """Generator over time chunks of decode(): yields (audio (B,1,n*256*4) | None, gen_mel (B,n_mels,n*4)) for
         successive windows of `chunk_tokens` token frames, each decoded with `halo_tokens` of context on both sides
@@ -388,9 +428,165 @@ class VQGAN(nn.Module):
     @torch.no_grad()
     def decode_chunked(self, indices, feature_lengths, chunk_tokens: int = 64, halo_tokens: Optional[int] = None,
                        noise: Optional[torch.Tensor] = None, return_audios: bool = True):
-        """decode() evaluated chunk by chunk (decode_stream) and concatenated: same result, bounded workspace."""
-        parts = list(self.decode_stream(indices, feature_lengths, chunk_tokens, halo_tokens, noise, return_audios))
+        """decode() evaluated window by window (each window re-run with `halo_tokens` of context on both sides and cropped) and
+        concatenated: same result, bounded workspace, no state.  decode_stream is the incremental form."""
+        parts = list(self._decode_windows(indices, feature_lengths, chunk_tokens, halo_tokens, noise, return_audios))
         mel = torch.cat([p[1] for p in parts], dim=-1)
         if return_audios:
             return torch.cat([p[0] for p in parts], dim=-1), mel
         return mel
+
+
+class StreamingDecoder:
+    """State of one incremental decode (VQGAN.streaming_decoder).  Time is counted in mel frames; `origin` is the absolute frame held in
+    column 0 of the state buffers (old columns are dropped once nothing reads them any more, so memory is bounded by the chunk size,
+    not by the stream length)."""
+
+    QUANT_HALO_TOKENS = 4        # ConvNeXt k7 at rates 2 and 4: 3 / 2 + 3 / 4 tokens of context on each side
+
+    def __init__(self, codec: VQGAN, batch: int, feature_lengths, return_audios: bool):
+        if codec.decoder is None:
+            raise ValueError("Decoder is not loaded")
+        if return_audios and codec.vocoder is None:
+            raise ValueError("Vocoder is not loaded")
+        self.codec, self.B, self.return_audios = codec, int(batch), return_audios
+        dec = codec.decoder
+        if dec.input_projection is not None:
+            raise NotImplementedError("streaming needs a decoder without input projection (input_channels == residual_channels)")
+        self.factor = math.prod(codec.quantizer.downsample_factor)
+        self.L, self.C = len(dec.residual_layers), dec.residual_channels
+        self.dils = [2 ** (i % dec.dilation_cycle) if dec.dilation_cycle else 1 for i in range(self.L)]
+        self.maxdil = max(self.dils)
+        self.voc_halo = codec.vocoder.receptive_field_frames() if return_audios else 0
+        self.up = math.prod(codec.vocoder.h.upsample_rates) if return_audios else 1
+        self.lengths = None
+        if feature_lengths is not None:
+            self.lengths = VQGAN._lengths(feature_lengths).to(torch.int64)
+        self.tokens = None            # every token received so far is kept only as long as the quantiser's context needs it
+        self.tok_origin = 0           # absolute index of tokens[..., 0]
+        self.n_tok = 0
+        self.origin = 0
+        self.cap = 0
+        self.prev = [0] * (self.L + 1)     # absolute frontier of every level
+        self.z_valid = 0                    # condition / input written up to here (absolute)
+        self.emitted = 0                    # mel frames handed out
+        self.noise_tail = None
+        self.finished = False
+
+    # -- buffers ---------------------------------------------------------------------------------------------------
+    def _ensure(self, upto: int, dev) -> None:
+        """make room for absolute frames < upto: drop columns nothing will read again, grow if that is not enough"""
+        need_from = max(0, min(self.prev[self.L] - self.maxdil, self.emitted - self.voc_halo))
+        if self.cap and upto - self.origin <= self.cap:
+            return
+        shift = need_from - self.origin
+        keep = max(0, self.z_valid - need_from)
+        want = upto - need_from
+        if self.cap == 0 or want > self.cap:
+            cap = max(512, 2 * want)
+            new = dict(hist=torch.zeros(self.L + 1, self.B, self.C, cap, dtype=torch.float32, device=dev),
+                       skip=torch.zeros(self.B, self.C, cap, dtype=torch.float32, device=dev),
+                       cond=torch.zeros(self.B, self.codec.decoder.condition_channels, cap, dtype=torch.float32, device=dev),
+                       mel=torch.zeros(self.B, self.codec.decoder.output_channels, cap, dtype=torch.float32, device=dev),
+                       scratch=torch.empty(2 * self.B * self.C * cap, dtype=torch.float32, device=dev))
+            if self.cap:
+                for k in ("hist", "skip", "cond", "mel"):
+                    new[k][..., :keep] = self.buf[k][..., shift:shift + keep]
+            self.buf, self.cap = new, cap
+        elif shift > 0:
+            for k in ("hist", "skip", "cond", "mel"):
+                self.buf[k][..., :keep] = self.buf[k][..., shift:shift + keep].clone()
+        self.origin = need_from
+
+    # -- one step ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def push(self, ids: torch.Tensor, noise: Optional[torch.Tensor] = None, final: bool = False):
+        """ids (B, G, n) int (n may be 0 with final=True) -> (audio (B, 1, m * up) | None, mel (B, n_mels, m)) for the m >= 0 frames that
+        became final with this chunk."""
+        codec, f = self.codec, self.factor
+        if self.finished:
+            raise RuntimeError("stream already finished")
+        _lib.require_cuda(ids, "indices")
+        dev = ids.device
+        n = ids.shape[2]
+        ids = ids.to(torch.int32)
+        self.tokens = ids if self.tokens is None else torch.cat([self.tokens, ids], dim=2)
+        self.n_tok += n
+        total_frames = self.n_tok * f
+        H = self.QUANT_HALO_TOKENS
+        # ---- quantiser: new condition frames [z_valid, z_new) from a token window with H tokens of context
+        z_new = total_frames if final else max(self.z_valid, (self.n_tok - H) * f)
+        self._ensure(total_frames, dev)
+        if noise is None:
+            noise = torch.randn(self.B, self.C, n * f, dtype=torch.float32, device=dev)
+        elif noise.shape != (self.B, self.C, n * f):
+            raise ValueError(f"noise must have shape {(self.B, self.C, n * f)}")
+        noise = noise.to(dev, torch.float32)
+        self.noise_tail = noise if self.noise_tail is None else torch.cat([self.noise_tail, noise], dim=2)   # frames [z_valid, total)
+        if z_new > self.z_valid:
+            lo_tok = max(0, self.z_valid // f - H)
+            win = self.tokens[:, :, lo_tok - self.tok_origin:].contiguous()
+            if self.lengths is not None:
+                wl = (self.lengths.to(dev) - lo_tok).clamp(min=0, max=win.shape[2])
+            else:
+                wl = torch.full((self.B,), win.shape[2], dtype=torch.int64, device=dev)
+            z, _ = codec.get_quantized_features_from_indices(win, wl)
+            a, b = self.z_valid - lo_tok * f, z_new - lo_tok * f
+            o = self.origin
+            self.buf["cond"][:, :, self.z_valid - o:z_new - o] = z[:, :, a:b]
+            x0 = self.noise_tail[:, :, :z_new - self.z_valid]
+            if self.lengths is not None:
+                t = torch.arange(self.z_valid, z_new, device=dev)[None, None, :]
+                x0 = x0 * (t < (self.lengths.to(dev) * f)[:, None, None]).to(torch.float32)
+            self.buf["hist"][0][:, :, self.z_valid - o:z_new - o] = x0
+            self.noise_tail = self.noise_tail[:, :, z_new - self.z_valid:]
+            self.z_valid = z_new
+            drop = max(0, self.z_valid // f - H - self.tok_origin)
+            if drop:
+                self.tokens, self.tok_origin = self.tokens[:, :, drop:], self.tok_origin + drop
+        # ---- decoder WaveNet: every block advances to its new frontier
+        nxt = [self.z_valid]
+        for d in self.dils:
+            nxt.append(self.z_valid if final else max(self.prev[len(nxt)], nxt[-1] - d))
+        if final or nxt[self.L] > self.prev[self.L]:
+            o = self.origin
+            prev = (C.c_int64 * (self.L + 1))(*[p - o for p in self.prev])
+            new = (C.c_int64 * (self.L + 1))(*[p - o for p in nxt])
+            dec = codec.decoder
+            with torch.cuda.device(dev):
+                h = dec.native()
+                b = self.buf
+                _lib.check(_lib.lib().dmel_wavenet_stream_step(h, b["hist"].data_ptr(), b["skip"].data_ptr(), b["cond"].data_ptr(),
+                                                               b["mel"].data_ptr(), b["scratch"].data_ptr(), self.B, self.cap, prev, new,
+                                                               _lib.stream_ptr()), "wavenet_stream_step")
+            if self.lengths is not None and nxt[self.L] > self.prev[self.L]:
+                t = torch.arange(self.prev[self.L], nxt[self.L], device=dev)[None, None, :]
+                m = (t < (self.lengths.to(dev) * f)[:, None, None]).to(torch.float32)
+                self.buf["mel"][:, :, self.prev[self.L] - o:nxt[self.L] - o] *= m
+            self.prev = nxt
+        # ---- emit: mel frames whose vocoder context exists
+        ready = self.prev[self.L]
+        e_new = ready if (final or not self.return_audios) else max(self.emitted, ready - self.voc_halo)
+        o = self.origin
+        mel = self.buf["mel"][:, :, self.emitted - o:e_new - o].clone()
+        audio = None
+        if self.return_audios:
+            if e_new > self.emitted:
+                lo = max(0, self.emitted - self.voc_halo)
+                hi = min(ready, e_new + self.voc_halo)
+                wav = codec.vocoder(self.buf["mel"][:, :, lo - o:hi - o].contiguous())
+                audio = wav[:, :, (self.emitted - lo) * self.up:(e_new - lo) * self.up]
+            else:
+                audio = torch.empty(self.B, 1, 0, dtype=torch.float32, device=dev)
+        self.emitted = e_new
+        if final:
+            self.finished = True
+        return audio, mel
+
+    def finish(self):
+        """no more tokens: flush everything that was waiting for right context"""
+        if self.tokens is None:
+            raise RuntimeError("finish() before any token")
+        G = self.tokens.shape[1]
+        empty = torch.empty(self.B, G, 0, dtype=torch.int32, device=self.tokens.device)
+        return self.push(empty, noise=torch.empty(self.B, self.C, 0, device=self.tokens.device), final=True)

@@ -2,8 +2,9 @@
   * alias_free_activation/torch/act.py:8-30 (Activation1d = UpSample1d -> act -> DownSample1d), and
   * alias_free_activation/cuda/activation1d.py:35-77 + anti_alias_activation_cuda.cu (fused, forward only),
 with the same sub-module / buffer names (`act`, `upsample.filter`, `downsample.lowpass.filter`).
-forward() is ONE HIP launch (csrc/aa_snake.hip); when gradients are required it is differentiable through the native backward
-kernel (dmel_aa_snake_backward_f32) -- the reference's fused kernel has none (cuda/activation1d.py:29-32)."""
+forward() is ONE HIP launch (csrc/aa_snake.hip) issued through torch.ops.dmel_hip.aa_snake; when gradients are required it is
+differentiable through the native backward kernel (dmel_aa_snake_backward_f32) -- the reference's fused kernel has none
+(cuda/activation1d.py:29-32)."""
 from __future__ import annotations
 
 import math
@@ -11,7 +12,7 @@ import math
 import torch
 from torch import nn
 
-from ..... import _lib
+from ..... import _lib, torch_ops  # noqa: F401  (registers torch.ops.dmel_hip.*)
 from ..activations import Snake, SnakeBeta
 
 
@@ -48,33 +49,6 @@ class _DownSample(nn.Module):
         self.lowpass = _FilterHolder(filt)
 
 
-class _AASnakeFn(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, x, alpha, beta, taps, logscale):
-        B, Cc, T = x.shape
-        y = torch.empty_like(x)
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().dmel_aa_snake_f32(x.data_ptr(), y.data_ptr(), alpha.data_ptr(), _lib.ptr(beta), taps.data_ptr(),
-                                                    int(logscale), B, Cc, T, _lib.stream_ptr()), "aa_snake")
-        ctx.save_for_backward(x, alpha, beta if beta is not None else torch.empty(0, device=x.device))
-        ctx.has_beta, ctx.taps, ctx.logscale = beta is not None, taps, logscale
-        return y
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, alpha, beta = ctx.saved_tensors
-        beta = beta if ctx.has_beta else None
-        B, Cc, T = x.shape
-        dy = dy.float().contiguous()
-        dx, da = torch.empty_like(x), torch.empty_like(alpha)
-        db = torch.empty_like(beta) if beta is not None else None
-        with torch.cuda.device(x.device):
-            _lib.check(_lib.lib().dmel_aa_snake_backward_f32(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), alpha.data_ptr(), _lib.ptr(beta),
-                                                             da.data_ptr(), _lib.ptr(db), ctx.taps.data_ptr(), int(ctx.logscale), B, Cc, T,
-                                                             _lib.stream_ptr()), "aa_snake_backward")
-        return dx, da, db, None, None
-
-
 class Activation1d(nn.Module):
     def __init__(self, activation, up_ratio: int = 2, down_ratio: int = 2, up_kernel_size: int = 12,
                  down_kernel_size: int = 12):
@@ -92,24 +66,9 @@ class Activation1d(nn.Module):
         _lib.require_cuda(x, "x")
         if x.ndim != 3 or x.shape[1] != self.act.in_features:
             raise ValueError(f"expected (B, {self.act.in_features}, T), got {tuple(x.shape)}")
-        x = x.float().contiguous()
-        alpha = self.act.alpha.to(device=x.device, dtype=torch.float32).contiguous()
-        beta = None
-        if isinstance(self.act, SnakeBeta):
-            beta = self.act.beta.to(device=x.device, dtype=torch.float32).contiguous()
-        taps = self.upsample.filter.detach().to("cpu", torch.float32).contiguous().view(-1)
-        if not torch.equal(taps, self.downsample.lowpass.filter.detach().cpu().float().view(-1)):
-            raise NotImplementedError("different up/down filters are not built")
-        needs_grad = torch.is_grad_enabled() and (x.requires_grad or alpha.requires_grad or (beta is not None and beta.requires_grad))
-        if needs_grad:
-            return _AASnakeFn.apply(x, alpha, beta, taps, bool(self.act.alpha_logscale))
-        with torch.no_grad():
-            return _AASnakeFn.forward(_NoCtx(), x, alpha.detach(), beta.detach() if beta is not None else None, taps,
-                                      bool(self.act.alpha_logscale))
-
-
-class _NoCtx:
-    """Stand-in for the autograd context on the inference path (nothing is saved)."""
-
-    def save_for_backward(self, *a):
-        pass
+        beta = self.act.beta if isinstance(self.act, SnakeBeta) else None
+        # torch.ops.dmel_hip.aa_snake (dmel_codec_amd/torch_ops.py): one launch; differentiable through the native backward kernel.
+        # The two filter buffers go in as they are -- the op keeps their 12 host taps cached per (storage, version), so there is no
+        # device-to-host copy (and no stream sync) per call; up and down filters may differ, as in fwd_cuda's signature.
+        return torch.ops.dmel_hip.aa_snake(x, self.act.alpha, beta, self.upsample.filter, self.downsample.lowpass.filter,
+                                           bool(self.act.alpha_logscale))

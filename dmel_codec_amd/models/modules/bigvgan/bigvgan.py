@@ -11,7 +11,7 @@ import json
 import torch
 from torch import nn
 
-from .... import _lib
+from .... import _lib, torch_ops  # noqa: F401  (registers torch.ops.dmel_hip.*)
 from .._native import NativeModule
 from . import activations
 from .alias_free_activation.act import Activation1d
@@ -169,6 +169,23 @@ class BigVGAN(NativeModule):
         _lib.check(_lib.lib().dmel_bigvgan_create(C.byref(handle), C.byref(cfg)), "bigvgan_create")
         return handle.value
 
+    def receptive_field_frames(self) -> int:
+        """Mel frames of context on EACH side beyond which an output sample does not depend on the input (every layer has finite
+        support): conv_pre 3 frames; per stage one input frame for the transposed conv (k = 2u, stride u) plus, at the stage's rate,
+        the widest AMP block: per layer pair 6 (anti-aliased activation) + d (k-1)/2 + 6 + (k-1)/2 samples; then activation_post 6 and
+        conv_post 3 samples.  Used by VQGAN.decode_stream to run the vocoder on a window and crop, bit-identically."""
+        h = self.h
+        frames, rate = 3.0, 1
+        widest = 0
+        for k, dils in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
+            widest = max(widest, sum(12 + d * (k - 1) // 2 + (k - 1) // 2 for d in dils))
+        for u in h.upsample_rates:
+            frames += 1.0 / rate
+            rate *= u
+            frames += widest / rate
+        frames += 9.0 / rate
+        return int(frames) + 2
+
     def set_streams(self, n_streams: int) -> None:
         """1: all kernels on the current stream; 3 (default): the AMP blocks of a stage overlap on side streams."""
         with torch.cuda.device(self._device()):
@@ -185,11 +202,9 @@ class BigVGAN(NativeModule):
         up = 1
         for u in self.h.upsample_rates:
             up *= u
-        y = torch.empty(B, 1, T * up, dtype=torch.float32, device=x.device)
         L = _lib.lib()
         with torch.cuda.device(x.device):
             h = self.native()
             ws = self._ws.get(L.dmel_bigvgan_workspace_bytes(h, B, T), x.device)
-            _lib.check(L.dmel_bigvgan_forward(h, x.data_ptr(), y.data_ptr(), B, T, ws.data_ptr(), ws.numel(),
-                                              _lib.stream_ptr()), "bigvgan_forward")
-        return y
+        # through PyTorch's dispatcher (dmel_codec_amd/torch_ops.py): torch.ops.dmel_hip.bigvgan_forward -> dmel_bigvgan_forward
+        return torch.ops.dmel_hip.bigvgan_forward(h, x, up, ws)

@@ -142,7 +142,7 @@ class DownsampleFiniteScalarQuantize(NativeModule):
         return h.value
 
     @torch.no_grad()
-    def encode(self, z: torch.Tensor, return_prequant: bool = False):
+    def encode(self, z: torch.Tensor, return_prequant: bool = False, return_latents: bool = False):
         """z (B*G, C, T) -> indices (B, G, T // prod(factors)) int32      (dowmsample_fsq.py:124-133)"""
         _lib.require_cuda(z, "z")
         cg = self.input_dim // self.groups
@@ -160,9 +160,11 @@ class DownsampleFiniteScalarQuantize(NativeModule):
             h = self.native()
             _lib.check(L.dmel_quantizer_set_strict(h, int(bool(self.strict_encode))), "quantizer_set_strict")
             ws = self._ws.get(L.dmel_quantizer_workspace_bytes(h, B, T), z.device)
-            _lib.check(L.dmel_quantizer_encode(h, z.data_ptr(), ids.data_ptr(), _lib.ptr(pre), B, T, ws.data_ptr(),
-                                               ws.numel(), _lib.stream_ptr()), "quantizer_encode")
-        return (ids, pre) if return_prequant else ids
+            lat = torch.empty(z.shape[0], cg, T4, dtype=torch.float32, device=z.device) if return_latents else None
+            _lib.check(L.dmel_quantizer_encode_ex(h, z.data_ptr(), ids.data_ptr(), _lib.ptr(pre), _lib.ptr(lat), B, T, ws.data_ptr(),
+                                                  ws.numel(), _lib.stream_ptr()), "quantizer_encode")
+        out = (ids,) + ((pre,) if return_prequant else ()) + ((lat,) if return_latents else ())
+        return out if len(out) > 1 else ids
 
     @torch.no_grad()
     def decode(self, indices: torch.Tensor) -> torch.Tensor:

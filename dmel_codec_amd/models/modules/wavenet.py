@@ -12,7 +12,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from ... import _lib
+from ... import _lib, torch_ops  # noqa: F401  (torch_ops registers torch.ops.dmel_hip.*)
 from ._native import NativeModule
 
 
@@ -251,11 +251,8 @@ class WaveNet(NativeModule):
 
         il, ol = lens(in_lengths), lens(out_lengths)
         L = _lib.lib()
-        y = torch.empty(N, self.output_channels, T, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):      # handle creation (weight upload, side streams) must happen on x's device
             h = self.native()
             ws = self._ws.get(L.dmel_wavenet_workspace_bytes(h, N, T), dev)
-            _lib.check(L.dmel_wavenet_forward(h, x.data_ptr(), _lib.ptr(condition), y.data_ptr(), N, T, _lib.ptr(il),
-                                              _lib.ptr(ol), group_repeat, ws.data_ptr(), ws.numel(), _lib.stream_ptr()),
-                       "wavenet_forward")
-        return y
+        # through PyTorch's dispatcher (dmel_codec_amd/torch_ops.py): torch.ops.dmel_hip.wavenet_forward -> dmel_wavenet_forward
+        return torch.ops.dmel_hip.wavenet_forward(h, x, condition, il, ol, group_repeat, self.output_channels, ws)

@@ -9,7 +9,7 @@ from typing import Optional
 import torch
 from torch import Tensor, nn
 
-from .. import _lib
+from .. import _lib, torch_ops  # noqa: F401  (registers torch.ops.dmel_hip.*)
 
 
 class LinearSpectrogram(nn.Module):
@@ -62,23 +62,16 @@ class LinearSpectrogram(nn.Module):
             y = y[:, 0]
         if y.ndim != 2:
             raise ValueError(f"expected (B, L) or (B, 1, L), got {tuple(y.shape)}")
-        y = y.float()
-        if y.stride(-1) != 1:
-            y = y.contiguous()
-        B, Ls = y.shape
-        L = _lib.lib()
         lens = None
         if lengths is not None:
             lens = lengths.reshape(-1).to(device=y.device, dtype=torch.int64).contiguous()
-            if lens.numel() != B:
+            if lens.numel() != y.shape[0]:
                 raise ValueError("lengths must have one entry per batch item")
-        with torch.cuda.device(y.device):        # the plan's tables live on the device that is current at creation
-            plan = self._get_plan()
-            T = L.dmel_stft_num_frames(plan, Ls)
-            out = torch.empty(B, self.num_mels, T, dtype=torch.float32, device=y.device)
-            _lib.check(L.dmel_stft_logmel_f32(plan, y.data_ptr(), y.stride(0), _lib.ptr(lens), out.data_ptr(), B, Ls,
-                                              _lib.stream_ptr()), "stft_logmel")
-        return out
+        # through PyTorch's dispatcher (dmel_codec_amd/torch_ops.py): torch.ops.dmel_hip.stft_logmel -> dmel_stft_logmel_f32; the plan
+        # (window, twiddles, sparse mel bands) is cached there per (configuration, device), as the reference caches its mel basis and
+        # window per device (spectrogram.py:43-56)
+        return torch.ops.dmel_hip.stft_logmel(y, lens, self.sample_rate, self.n_fft, self.win_length, self.hop_length, self.num_mels,
+                                              float(self.f_min or 0.0), float(self.f_max) if self.f_max else 0.0)
 
 
 class LogMelSpectrogram(nn.Module):

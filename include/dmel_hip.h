@@ -81,17 +81,19 @@ int dmel_stft_logmel_f32(const dmel_stft_plan* plan, const float* audio, int64_t
  * torch Activation1d (alias_free_activation/torch/act.py:25-30): x2 up (12-tap kaiser-sinc, replicate pad)
  * -> x + 1/(b+1e-9) sin^2(a x) -> x2 down (12 taps, replicate pad 5/6).  alpha/beta: (C) as stored in the
  * state dict; logscale != 0 applies exp() as the reference does.  beta == NULL means Snake (beta := alpha).
- * filter_host: 12 taps used for both directions (the reference registers the same filter twice).
+ * up_filter12_host / down_filter12_host: the 12 taps of UpSample1d.filter and DownSample1d.lowpass.filter (host pointers; they
+ * become launch constants) -- the two arguments of fwd_cuda(input, up_filter, down_filter, alpha, beta)
+ * (anti_alias_activation.cpp:19-23); the reference registers the same kaiser-sinc taps for both.
  * ---------------------------------------------------------------------------------------------- */
-int dmel_aa_snake_f32(const float* x, float* y, const float* alpha, const float* beta, const float* filter12_host,
-                      int logscale, int B, int C, int64_t T, void* stream);
+int dmel_aa_snake_f32(const float* x, float* y, const float* alpha, const float* beta, const float* up_filter12_host,
+                      const float* down_filter12_host, int logscale, int B, int C, int64_t T, void* stream);
 /* Backward of dmel_aa_snake_f32 (the reference's fused kernel has none: alias_free_activation/cuda/activation1d.py:29-32;
  * SURVEY.md section 8(f) rank 1, C-ABI row `aa_snake(+_bwd)`): dx (B, C, T), dalpha (C), dbeta (C; NULL exactly when beta is NULL,
  * i.e. Snake, whose single parameter then receives both contributions).  Gradients are with respect to the STORED parameters
  * (the log-scale ones when logscale != 0).  dalpha / dbeta are overwritten.  Summation order is not fixed (atomics). */
 int dmel_aa_snake_backward_f32(const float* x, const float* dy, float* dx, const float* alpha, const float* beta /*nullable*/,
-                               float* dalpha, float* dbeta /*nullable*/, const float* filter12_host, int logscale, int B, int C,
-                               int64_t T, void* stream);
+                               float* dalpha, float* dbeta /*nullable*/, const float* up_filter12_host,
+                               const float* down_filter12_host, int logscale, int B, int C, int64_t T, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Module handles.  Weights are handed over as HOST fp32 arrays under the reference's state-dict key names
@@ -150,6 +152,21 @@ int dmel_wavenet_backward_hooked(const dmel_wavenet* m, const float* x, const fl
                                  float* dcondition /*nullable*/, float* grads, int N, int64_t T, void* workspace,
                                  size_t workspace_bytes, void* stream, dmel_grad_ready_fn on_ready, void* user);
 
+/* Incremental (streaming) forward with state carry -- SURVEY.md section 8(f) rank 2: the LM emits tokens, the codec decodes while it
+ * does (the reference decodes once at the end, models/lm_lit_modules.py:467-471).  Every block is a "same"-padded convolution, so block
+ * l's output at time t needs block l-1's output up to t + dilation_l: instead of re-running a halo of old frames through the stack for
+ * every chunk, the caller keeps the OUTPUT HISTORY of every block and each step only computes the new columns of every block.
+ *   hist (L + 1, N, C, cap): hist[0] = the (masked) input x_0 (after input_projection, when the model has one: not supported here),
+ *                            hist[l] = output of block l; time axis in window coordinates [0, cap)
+ *   skip (N, C, cap): running sum of the blocks' skip outputs;  cond (N, Ccond, cap) or NULL;  y (N, Cout, cap)
+ *   prev[l], next[l], l = 0..L: columns [0, prev[l]) of level l are already valid; the call makes [prev[l], next[l]) valid.
+ *     next[0] = how far x_0 / cond have been written by the caller; mid-stream next[l] <= next[l-1] - dilation_l (checked);
+ *     at the end of the sequence next[l] = next[0] = total length for every l (zero padding past the end, like the whole-sequence call).
+ *   y gets columns [prev[L], next[L]).  scratch: N * 2 C * cap floats.
+ * Numerically identical to dmel_wavenet_forward column by column (same kernels, same reduction order). */
+int dmel_wavenet_stream_step(const dmel_wavenet* m, float* hist, float* skip, const float* cond /*nullable*/, float* y, float* scratch,
+                             int N, int64_t cap, const int64_t* prev, const int64_t* next, void* stream);
+
 /* ConvNeXtBlock (models/modules/firefly.py:337-402; C-ABI row `convnext_block`), standalone: y = x + gamma * pwconv2(gelu(pwconv1(
  * LayerNorm_C(dwconv7(x))))), x / y (N, dim, T).  set_tensor keys: dwconv.weight (dim,1,7), dwconv.bias, norm.weight, norm.bias,
  * pwconv1.weight (4 dim, dim), pwconv1.bias, pwconv2.weight (dim, 4 dim), pwconv2.bias, gamma.  The training entry points follow the
@@ -190,6 +207,10 @@ size_t dmel_quantizer_workspace_bytes(const dmel_quantizer* q, int B, int64_t T)
  * (G, B, T4, n_levels) fp32, the bounded value that is rounded (for the near-tie analysis of the tests). */
 int dmel_quantizer_encode(const dmel_quantizer* q, const float* z, int32_t* ids, float* prequant, int B, int64_t T,
                           void* workspace, size_t workspace_bytes, void* stream);
+/* The same, additionally returning the down-sampled features the FSQ sees -- latents (B*G, C, T4), nullable -- so that a checker can
+ * feed another FSQ implementation exactly the same input (strict-mode parity test). */
+int dmel_quantizer_encode_ex(const dmel_quantizer* q, const float* z, int32_t* ids, float* prequant /*nullable*/,
+                             float* latents /*nullable*/, int B, int64_t T, void* workspace, size_t workspace_bytes, void* stream);
 /* ids (B, G, T4) -> z (B, G*C, T4*prod(factors)) */
 int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids, float* z, int B, int64_t T4,
                           void* workspace, size_t workspace_bytes, void* stream);

@@ -34,7 +34,7 @@ def test_every_declared_symbol_is_exported_and_bound(L):
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/dmel_hip.h but not exported by libdmel_hip.so"
         assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype"
-    assert L.dmel_abi_version() == 1
+    assert L.dmel_abi_version() == 2
 
 
 def test_errors_are_loud_not_fallbacks(L):

@@ -71,15 +71,13 @@ def test_strict_encode_depends_only_on_the_features(dev):
         sd = cpu_sd(q)
         torch.manual_seed(6)
         z = torch.randn(B * G, Cg, T4 * 4)
-        # run the GPU front half (down-sampling convs + ConvNeXt) and hand ITS output to the oracle's FSQ: same features on both sides
-        ids, pre = q.to(dev).encode(z.to(dev), return_prequant=True)
-        feats = ref_cpu.quantizer_downsample(sd, "", z, (2, 2))                     # CPU features: close, not identical
-        ids_cpu_feats, pre_cpu = ref_cpu.quantizer_encode(sd, "", z, G, levels, (2, 2), prebound, return_prequant=True, strict=True)
-        n_diff, n_bad, n_tie = near_tie_report(ids, ids_cpu_feats, pre_cpu)
+        ids, pre, lat = q.to(dev).encode(z.to(dev), return_prequant=True, return_latents=True)
+        # (a) CPU features (close to the GPU's, not identical): ids agree away from rounding boundaries
+        ids_cpu, pre_cpu = ref_cpu.quantizer_encode(sd, "", z, G, levels, (2, 2), prebound, return_prequant=True, strict=True)
+        n_diff, n_bad, n_tie = near_tie_report(ids, ids_cpu, pre_cpu)
         assert n_bad == 0 and (pre.cpu() - pre_cpu).abs().max() < 5e-5
-        del feats
-        # identical features: take them from the GPU via the training forward's latents (the tensor the FSQ sees)
-        lat = q(z.to(dev)).latents.detach().cpu()                                  # (B, G*Cg, T4)
+        # (b) IDENTICAL features (the GPU's own down-sampled latents, handed to the oracle's FSQ): everything must be equal bit for bit
+        lat = lat.cpu().reshape(B, G * Cg, T4)                                      # "(b g) f t -> b (g f) t"
         out = ref_cpu.grouped_fsq_encode(sd, "residual_fsq.", lat.mT, G, levels, prebound, return_prequant=True, strict=True)
         ids_same = out[0].permute(1, 0, 3, 2).reshape(B, G, T4)
         assert torch.equal(pre.cpu(), out[1]), float((pre.cpu() - out[1]).abs().max())

@@ -179,3 +179,69 @@ def test_checkpoint_wire_formats_round_trip(dev, tmp_path):
     wav_b, mel_b = b.decode(ids_b, il_b, return_audios=True, noise=noise)
     assert torch.equal(ids_a, ids_b) and torch.equal(il_a, il_b)
     assert torch.equal(mel_a, mel_b) and torch.equal(wav_a, wav_b)
+
+
+# ------------------------------------------------------------------------------------ torch.ops.dmel_hip.* (dispatcher registration)
+def test_torch_ops_are_registered_and_match_the_oracle(dev):
+    """Every hot-path op is callable as torch.ops.dmel_hip.<name> (torch.library registration over the C ABI; the reference exposes its
+    one native op the same way, anti_alias_activation.cpp:19-23 / load.py:31-48): one check per op against the CPU oracle, plus
+    autograd through the ops that have a native backward, and a fake-tensor (shape propagation) call for each."""
+    import torch.nn.functional as F
+    from oracle import ref_cpu
+    from conftest import rel_err
+    import dmel_codec_amd.torch_ops  # noqa: F401
+    ops = torch.ops.dmel_hip
+    g = torch.Generator().manual_seed(0)
+    # --- anti_alias_activation_forward == fwd_cuda(input, up_filter, down_filter, alpha, beta), log-scale parameters; different filters
+    x = torch.randn(2, 6, 333, generator=g)
+    alpha, beta = torch.randn(6, generator=g) * 0.3, torch.randn(6, generator=g) * 0.3
+    up = ref_cpu.aa_filter12()
+    down = up.flip(-1) * 0.9 + 0.01                              # NOT the same taps: fwd_cuda takes two filters
+    ref = ref_cpu.activation1d(x, alpha, beta, up, down, logscale=True)
+    y = ops.anti_alias_activation_forward(x.to(dev), up.to(dev), down.to(dev), alpha.to(dev), beta.to(dev))
+    assert rel_err(y, ref) < 1e-5
+    # --- aa_snake with autograd (native backward kernel) against autograd through the oracle in float64
+    x64, a64, b64 = x.double().requires_grad_(), alpha.double().requires_grad_(), beta.double().requires_grad_()
+    ref_cpu.activation1d(x64, a64, b64, up.double(), down.double(), logscale=True).square().sum().backward()
+    xd, ad, bd = x.to(dev).requires_grad_(), alpha.to(dev).requires_grad_(), beta.to(dev).requires_grad_()
+    ops.aa_snake(xd, ad, bd, up.to(dev), down.to(dev), True).square().sum().backward()
+    assert rel_err(xd.grad, x64.grad) < 2e-5 and rel_err(ad.grad, a64.grad) < 1e-4 and rel_err(bd.grad, b64.grad) < 1e-4
+    # --- conv1d_dilated + backward
+    w, b = torch.randn(48, 24, 7, generator=g) / (24 * 7) ** 0.5, torch.randn(48, generator=g) * 0.1
+    xc = torch.randn(3, 24, 200, generator=g)
+    xc64, w64, bb64 = xc.double().requires_grad_(), w.double().requires_grad_(), b.double().requires_grad_()
+    F.conv1d(xc64, w64, bb64, dilation=3, padding=9).square().sum().backward()
+    xcd, wd, bdv = xc.to(dev).requires_grad_(), w.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    yc = ops.conv1d_dilated(xcd, wd, bdv, 3)
+    assert rel_err(yc, F.conv1d(xc64, w64, bb64, dilation=3, padding=9).detach()) < 2e-5
+    yc.square().sum().backward()
+    assert rel_err(xcd.grad, xc64.grad) < 2e-5 and rel_err(wd.grad, w64.grad) < 2e-5 and rel_err(bdv.grad, bb64.grad) < 2e-5
+    # --- stft_logmel
+    audio = torch.randn(2, 24000, generator=g) * 0.1
+    mel_ref = ref_cpu.stft_logmel(audio[:, None, :], 24000, 1024, 1024, 256, 80, 0.0, None)
+    mel = ops.stft_logmel(audio.to(dev), None, 24000, 1024, 1024, 256, 80, 0.0, 0.0)
+    assert mel.shape == mel_ref.shape and rel_err(mel.exp(), mel_ref.exp()) < 1e-4
+    # --- module-level ops on handles owned by the mirrors (their forward() goes through the same ops)
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    m = WaveNet(input_channels=10, residual_channels=32, residual_layers=3).to(dev)
+    xw = torch.randn(4, 10, 50, device=dev)
+    with torch.cuda.device(dev):
+        h = m.native()
+        ws = torch.empty(_lib_ws(h, 4, 50), dtype=torch.uint8, device=dev)
+    yw = ops.wavenet_forward(h, xw, None, None, None, 1, m.output_channels, ws)
+    with torch.no_grad():
+        assert torch.equal(yw, m(xw))
+    assert rel_err(yw, ref_cpu.wavenet_forward({k: v.detach().cpu() for k, v in m.state_dict().items()}, "", xw.cpu(), 3)) < 1e-4
+    # --- fake tensors: shapes propagate without touching the GPU library (what torch.compile's tracing needs)
+    from torch._subclasses.fake_tensor import FakeTensorMode
+    with FakeTensorMode():
+        fx = torch.empty(2, 6, 333, device="cuda")
+        assert ops.aa_snake(fx, torch.empty(6, device="cuda"), None, torch.empty(1, 1, 12), torch.empty(1, 1, 12), True).shape == (2, 6, 333)
+        assert ops.stft_logmel(torch.empty(3, 24000, device="cuda"), None, 24000, 1024, 1024, 256, 100, 0.0, 12000.0).shape == (3, 100, 93)
+        assert ops.conv1d_dilated(torch.empty(1, 24, 99, device="cuda"), torch.empty(48, 24, 7, device="cuda"), None, 3).shape == (1, 48, 99)
+        assert ops.bigvgan_forward(0, torch.empty(2, 80, 10, device="cuda"), 256, torch.empty(8, dtype=torch.uint8, device="cuda")).shape == (2, 1, 2560)
+
+
+def _lib_ws(h, N, T):
+    from dmel_codec_amd import _lib
+    return _lib.lib().dmel_wavenet_workspace_bytes(h, N, T)

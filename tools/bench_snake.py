@@ -14,11 +14,11 @@ for (B, C, T) in ((32, 256, 736), (32, 128, 5888), (32, 64, 11776), (32, 32, 235
     al, be = torch.randn(C, device=dev) * 0.3, torch.randn(C, device=dev) * 0.3
     st = _lib.stream_ptr()
     for _ in range(3):
-        _lib.check(L.dmel_aa_snake_f32(x.data_ptr(), y.data_ptr(), al.data_ptr(), be.data_ptr(), taps.data_ptr(), 1, B, C, T, st))
+        _lib.check(L.dmel_aa_snake_f32(x.data_ptr(), y.data_ptr(), al.data_ptr(), be.data_ptr(), taps.data_ptr(), taps.data_ptr(), 1, B, C, T, st))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20):
-        _lib.check(L.dmel_aa_snake_f32(x.data_ptr(), y.data_ptr(), al.data_ptr(), be.data_ptr(), taps.data_ptr(), 1, B, C, T, st))
+        _lib.check(L.dmel_aa_snake_f32(x.data_ptr(), y.data_ptr(), al.data_ptr(), be.data_ptr(), taps.data_ptr(), taps.data_ptr(), 1, B, C, T, st))
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 20

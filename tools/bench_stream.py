@@ -1,5 +1,6 @@
-"""Streaming decode benchmark (BASELINE.json configs[4], codec side): token ids (1, G, T4) -> audio in halo'd chunks.
-Reports the latency to the first audio chunk and the sustained audio-seconds per second at batch 1."""
+"""Streaming decode benchmark (BASELINE.json configs[4], codec side): token ids (1, G, T4) arrive in chunks, audio leaves as soon as its
+right context exists (VQGAN.decode_stream: WaveNet state carry + windowed vocoder).  Reports the latency from the first token to the
+first audio, the sustained audio-seconds per second at batch 1, and the windowed (stateless, halo re-run) form for comparison."""
 import json, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,21 +12,37 @@ g = torch.Generator().manual_seed(5)
 T4 = 469                                      # 20 s of audio at 23.4 token frames per second
 ids = torch.randint(0, 175, (1, 10, T4), generator=g, dtype=torch.int32).to(dev)
 flen = torch.tensor([T4], device=dev)
-for chunk in (32, 64, 128):
+for chunk in (8, 32, 64, 128):
     list(codec.decode_stream(ids, flen, chunk_tokens=chunk))      # warm-up (handles, workspaces)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    first = None
-    n = 0
-    for a, m in codec.decode_stream(ids, flen, chunk_tokens=chunk):
-        a.cpu() if first is None else None       # first chunk: include the device->host hand-off
-        if first is None:
-            first = time.perf_counter() - t0
+    first, first_tokens = None, None
+    n = fed = 0
+    dec = codec.streaming_decoder(1, flen)
+    for a0 in range(0, T4, chunk):
+        a, m = dec.push(ids[:, :, a0:a0 + chunk])
+        fed = min(T4, a0 + chunk)
+        if first is None and a.shape[-1]:
+            a.cpu()                               # first audio: include the device->host hand-off
+            first, first_tokens = time.perf_counter() - t0, fed
         n += a.shape[-1]
+    a, m = dec.finish()
+    n += a.shape[-1]
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(json.dumps({"chunk_tokens": chunk, "halo_tokens": codec.STREAM_HALO_TOKENS, "first_chunk_ms": round(first * 1e3, 2),
-                      "audio_s": round(n / 24000, 2), "audio_sec_per_sec": round(n / 24000 / el, 1)}))
+    print(json.dumps({"mode": "state carry", "chunk_tokens": chunk, "first_audio_ms": round(first * 1e3, 2), "first_audio_after_tokens": first_tokens,
+                      "audio_s": round(n / 24000, 2), "audio_sec_per_sec": round(n / 24000 / el, 1)}), flush=True)
+for chunk in (32, 64, 128):
+    codec.decode_chunked(ids, flen, chunk_tokens=chunk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    a, _ = codec.decode_chunked(ids, flen, chunk_tokens=chunk)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    print(json.dumps({"mode": "windows re-run with halo", "chunk_tokens": chunk, "halo_tokens": codec.STREAM_HALO_TOKENS,
+                      "audio_sec_per_sec": round(a.shape[-1] / 24000 / el, 1)}), flush=True)
+codec.decode(ids, flen, return_audios=True)
+torch.cuda.synchronize()
 t0 = time.perf_counter()
 a, _ = codec.decode(ids, flen, return_audios=True)
 torch.cuda.synchronize()
