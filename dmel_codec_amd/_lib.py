@@ -49,6 +49,8 @@ PROTOTYPES = {
     "dmel_stft_plan_mel_basis": (C.c_int, [vp, vp]),
     "dmel_stft_num_frames": (C.c_int64, [vp, C.c_int64]),
     "dmel_stft_logmel_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int, C.c_int64, vp]),
+    "dmel_resample_f32": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, vp]),
+    "dmel_stft_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_aa_snake_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_aa_snake_backward_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_discriminator_create": (C.c_int, [C.POINTER(vp)]),
@@ -59,6 +61,7 @@ PROTOTYPES = {
     "dmel_discriminator_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int64]),
     "dmel_discriminator_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_discriminator_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_discriminator_set_train_precision": (C.c_int, [vp, C.c_int]),
     "dmel_discriminator_refresh": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), vp]),
     "dmel_discriminator_train_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int, C.c_int64]),
     "dmel_discriminator_grad_floats": (C.c_int64, [vp]),
@@ -69,6 +72,7 @@ PROTOTYPES = {
     "dmel_convnext_destroy": (None, [vp]),
     "dmel_convnext_set_tensor": (C.c_int, [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]),
     "dmel_convnext_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_convnext_set_train_precision": (C.c_int, [vp, C.c_int]),
     "dmel_convnext_finalize": (C.c_int, [vp]),
     "dmel_convnext_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_convnext_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
@@ -81,6 +85,7 @@ PROTOTYPES = {
     "dmel_wavenet_destroy": (None, [vp]),
     "dmel_wavenet_set_precision": (C.c_int, [vp, C.c_int]),
     "dmel_wavenet_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_wavenet_set_train_precision": (C.c_int, [vp, C.c_int]),
     "dmel_wavenet_refresh": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), vp]),
     "dmel_wavenet_train_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_wavenet_grad_floats": (C.c_int64, [vp]),
@@ -103,6 +108,7 @@ PROTOTYPES = {
     "dmel_quantizer_encode_ex": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_quantizer_decode": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_quantizer_enable_training": (C.c_int, [vp, C.c_int]),
+    "dmel_quantizer_set_train_precision": (C.c_int, [vp, C.c_int]),
     "dmel_quantizer_refresh": (C.c_int, [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(vp), vp]),
     "dmel_quantizer_train_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_quantizer_grad_floats": (C.c_int64, [vp]),

@@ -67,6 +67,13 @@ ProfScope::~ProfScope() {
 using namespace dmel;
 
 extern "C" const char* dmel_last_error(void) { return g_err.c_str(); }
+namespace dmel {
+int& train_precision_override() {
+  static thread_local int v = -1;
+  return v;
+}
+}  // namespace dmel
+
 extern "C" int dmel_abi_version(void) { return 2; }   // 2: dmel_aa_snake_* take separate up / down filters; hooked backward; strict encode
 
 extern "C" int dmel_prof_enable(int on) {

@@ -78,6 +78,19 @@ struct ProfScope {
   hipStream_t stream;
 };
 
+// Training precision of the calling thread for the duration of one training entry point (dmel_*_forward_train / _backward):
+// DMEL_PRECISION_BF16 makes every convolution launched inside -- forward, backward-data and the long-row weight gradients -- run with
+// bf16-rounded operands and fp32 accumulation (what `precision: bf16-mixed` autocast does to the reference's conv1d / conv2d); -1 = no
+// override (each launch's own precision).  Thread-local: handles stay re-entrant.
+int& train_precision_override();
+struct TrainPrecisionScope {
+  int saved;
+  explicit TrainPrecisionScope(int precision) : saved(train_precision_override()) {
+    train_precision_override() = precision == DMEL_PRECISION_BF16 ? DMEL_PRECISION_BF16 : -1;
+  }
+  ~TrainPrecisionScope() { train_precision_override() = saved; }
+};
+
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // Bump allocator over the caller's workspace.

@@ -136,7 +136,15 @@ constexpr int kSpRow = 9;         // uint4 units per LDS row: 64 bf16 + 8 pad ->
 __device__ __forceinline__ uint32_t wg_pack_hi16(float lo, float hi) {
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
+template <int NP>
 __device__ __forceinline__ void wg_split_store(const float (&v)[8], uint4* plane0, int plane_stride, int idx) {
+  if constexpr (NP == 1) {
+    wg_bf16x8 p;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) p[e] = (__bf16)v[e];
+    plane0[idx] = __builtin_bit_cast(uint4, p);
+    return;
+  }
   uint32_t p1[4], p2[4], p3[4];
 #pragma unroll
   for (int e = 0; e < 8; e += 2) {
@@ -156,17 +164,18 @@ __device__ __forceinline__ void wg_split_store(const float (&v)[8], uint4* plane
 // XS = a.xstride (1 or 2); workgroup tile (64 MT) x (64 NT) output x input channels, 2 x 2 waves of (32 MT) x (32 NT); KS samples per
 // staged step.  <1, 1, 64>: the fp32 kernel's tile (default).  <2, 2, 32>: 128 x 128, twice the flops per byte moved from L2 (opt-in).
 // grid (ceil(Cin / (64 NT)), ceil(Cout / (64 MT)), taps * slices); a.chunks_per_item counts KS-sample steps.
-template <int XS, int MT, int NT, int KS>
+// NP = 3: split fp32 (exact products); NP = 1: operands rounded to bf16 (round to nearest even), one MFMA per block -- the bf16 training mode
+template <int XS, int MT, int NT, int KS, int NP = 3>
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
   constexpr int UR = KS / 8 + 1;                                 // uint4 units per LDS row incl. one pad unit: conflict-free 128-bit reads
   constexpr int RM = 64 * MT, RN = 64 * NT;                      // staged rows of dy / x
   constexpr int kPlaneD = RM * UR, kPlaneX = RN * UR;            // uint4 units per piece plane
   constexpr int G = KS / 8, RP = 256 / G;                        // 8-sample groups per row, rows per staging pass
   constexpr int PD = RM / RP, PX = RN / RP;                      // staging passes
-  static_assert(RM % RP == 0 && RN % RP == 0 && 3 * (kPlaneD + kPlaneX) * 16 <= 65536, "tile does not fit");
-  __shared__ uint4 lds[3 * (kPlaneD + kPlaneX)];                 // [operand][piece][row][unit]
+  static_assert(RM % RP == 0 && RN % RP == 0 && NP * (kPlaneD + kPlaneX) * 16 <= 65536, "tile does not fit");
+  __shared__ uint4 lds[NP * (kPlaneD + kPlaneX)];                 // [operand][piece][row][unit]
   uint4* const dys = lds;
-  uint4* const xs = lds + 3 * kPlaneD;
+  uint4* const xs = lds + NP * kPlaneD;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int ci0 = blockIdx.x * RN, co0 = blockIdx.y * RM;
@@ -263,14 +272,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (md[S][ps] >> e) & 1 ? rd[S][ps][e] : 0.f;
-      wg_split_store(v, dys, kPlaneD, (srow + RP * ps) * UR + sg);
+      wg_split_store<NP>(v, dys, kPlaneD, (srow + RP * ps) * UR + sg);
     }
 #pragma unroll
     for (int ps = 0; ps < PX; ++ps) {
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = (mx[S][ps] >> e) & 1 ? rx[S][ps][e] : 0.f;
-      wg_split_store(v, xs, kPlaneX, (srow + RP * ps) * UR + sg);
+      wg_split_store<NP>(v, xs, kPlaneX, (srow + RP * ps) * UR + sg);
     }
     __syncthreads();
     fetch(set, min(c + 2, c_end - 1));      // unconditional (the tail re-reads the last step): keeps the load count per step static
@@ -278,9 +287,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
     const uint4* bp = xs + (wn * 32 * NT + r31) * UR + hh;
 #pragma unroll
     for (int kk = 0; kk < KS / 16; ++kk) {
-      wg_bf16x8 af[MT][3], bf[NT][3];
+      wg_bf16x8 af[MT][NP], bf[NT][NP];
 #pragma unroll
-      for (int pc = 0; pc < 3; ++pc) {
+      for (int pc = 0; pc < NP; ++pc) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) af[mi][pc] = __builtin_bit_cast(wg_bf16x8, ap[pc * kPlaneD + mi * 32 * UR + 2 * kk]);
 #pragma unroll
@@ -288,12 +297,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
       }
       constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
 #pragma unroll
-      for (int u = 0; u < 6; ++u)
+      for (int u = 0; u < (NP == 3 ? 6 : 1); ++u)
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
           for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][PA[u]], bf[ni][PB[u]], acc[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][NP == 3 ? PA[u] : 0], bf[ni][NP == 3 ? PB[u] : 0], acc[mi][ni], 0, 0, 0);
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -339,7 +348,10 @@ static void launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.ipc = a.T <= 32 ? kWgK / a.T : 1;
   // short rows are mostly boundary steps (scalar loads in the split kernel): they stay on the fp32-MFMA kernel
   const bool split = a.ipc == 1 && !wgrad_native_only() && a.xstride <= 2 && a.T >= 256;
-  const bool big = split && a.Cout >= 128 && a.Cin >= 128 && wgrad_big_tile();
+  // bf16 training mode (TrainPrecisionScope): long rows take the one-piece instantiation of the split kernel; short rows (the 92-frame
+  // WaveNet GEMMs, packed image rows) stay on the exact fp32-MFMA kernel, which is at least as accurate
+  const bool bf16 = split && train_precision_override() == DMEL_PRECISION_BF16;
+  const bool big = split && !bf16 && a.Cout >= 128 && a.Cin >= 128 && wgrad_big_tile();
   const int tile = big ? 128 : kWgTile, ks = big ? 32 : kWgK;
   a.chunks_per_item = (a.T + ks - 1) / ks;
   const int tm = (a.Cout + tile - 1) / tile, tn = (a.Cin + tile - 1) / tile;
@@ -356,6 +368,8 @@ static void launch_wgrad_any(WgArgs a, hipStream_t st) {
   else if (!split) hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
   else if (big && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 2, 2, 32>), grid, dim3(256), 0, st, a);
   else if (big) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 2, 2, 32>), grid, dim3(256), 0, st, a);
+  else if (bf16 && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64, 1>), grid, dim3(256), 0, st, a);
+  else if (bf16) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1, 1, 64, 1>), grid, dim3(256), 0, st, a);
   else if (a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1, 1, 64>), grid, dim3(256), 0, st, a);
 }

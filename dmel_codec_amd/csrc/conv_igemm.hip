@@ -943,7 +943,8 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   const double rows_real = (d.mode == EPI_LINEAR ? (double)d.C * d.phases : 2.0 * d.C);
   ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, 0.0);
   static const int native_fp32 = [] { const char* e = getenv("DMEL_CONV_FP32_MFMA"); return e ? atoi(e) : 0; }();
-  if (r.precision == DMEL_PRECISION_BF16) return launch_bf16_any<1>(ka, d.mode, r.B, r.Tcols, stream);
+  if (r.precision == DMEL_PRECISION_BF16 || train_precision_override() == DMEL_PRECISION_BF16)
+    return launch_bf16_any<1>(ka, d.mode, r.B, r.Tcols, stream);
   // fp32: the split kernel is the default everywhere (after the wait-placement fixes it also wins on the 32-row, K < 128
   // layers of the last vocoder stage: 58 vs 72 us); the native fp32-MFMA kernels serve DMEL_PRECISION_FP32_MFMA
   if (r.precision == DMEL_PRECISION_FP32 && !native_fp32)

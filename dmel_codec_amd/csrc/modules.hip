@@ -108,6 +108,7 @@ struct dmel_wavenet {
   PackedConv in_proj, skip_proj, out_proj;
   std::vector<PackedConv> gate, resskip;
   int precision = 0;
+  int train_precision = 0;     // DMEL_PRECISION_BF16: bf16 training mode (dmel_wavenet_set_train_precision)
   // training path (enable_training before finalize): unfused forward images that expose the gate pre-activations, and the
   // transposed images that turn every backward-data into a forward convolution
   bool train = false, train_ready = false;
@@ -262,6 +263,11 @@ static int wavenet_pack_training(dmel_wavenet* m) {
   return DMEL_OK;
 }
 
+extern "C" int dmel_wavenet_set_train_precision(dmel_wavenet* m, int precision) {
+  DMEL_CHECK_ARG(m && (precision == DMEL_PRECISION_FP32 || precision == DMEL_PRECISION_BF16), "wavenet_set_train_precision: DMEL_PRECISION_FP32 or DMEL_PRECISION_BF16");
+  m->train_precision = precision;
+  return DMEL_OK;
+}
 extern "C" int dmel_wavenet_enable_training(dmel_wavenet* m, int on) {
   DMEL_CHECK_ARG(m, "NULL handle");
   m->train = on != 0;
@@ -627,6 +633,7 @@ extern "C" int dmel_wavenet_grad_slot(const dmel_wavenet* m, const char* key, in
 
 extern "C" int dmel_wavenet_forward_train(const dmel_wavenet* m, const float* x, const float* condition, float* y, int N, int64_t T,
                                           void* workspace, size_t workspace_bytes, void* stream) {
+  TrainPrecisionScope train_scope(m ? m->train_precision : 0);
   DMEL_CHECK_ARG(m && x && y && workspace, "wavenet_forward_train: NULL argument");
   if (!m->ready || !m->train_ready) { set_error("wavenet_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG((m->Ccond != 0) == (condition != nullptr), "wavenet_forward_train: condition tensor does not match the configuration");
@@ -682,6 +689,7 @@ extern "C" int dmel_wavenet_backward(const dmel_wavenet* m, const float* x, cons
 extern "C" int dmel_wavenet_backward_hooked(const dmel_wavenet* m, const float* x, const float* condition, const float* dy, float* dx,
                                             float* dcondition, float* grads, int N, int64_t T, void* workspace,
                                             size_t workspace_bytes, void* stream, dmel_grad_ready_fn on_ready, void* user) {
+  TrainPrecisionScope train_scope(m ? m->train_precision : 0);
   DMEL_CHECK_ARG(m && x && dy && grads && workspace, "wavenet_backward: NULL argument");
   if (!m->ready || !m->train_ready) { set_error("wavenet_backward: enable_training + finalize first"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG((m->Ccond != 0) == (condition != nullptr), "wavenet_backward: condition tensor does not match the configuration");
@@ -829,6 +837,7 @@ int run_convnext(const ConvNeXt& cx, const float* x, float* y, float* h1, float*
 
 // ---- standalone ConvNeXtBlock handle (firefly.py:337-402), inference and training -----------------------------------
 struct dmel_convnext {
+  int train_precision = 0;     // DMEL_PRECISION_BF16: bf16 training mode
   int C = 0;
   TensorStore ts;
   bool ready = false, train = false, train_ready = false;
@@ -855,6 +864,11 @@ extern "C" int dmel_convnext_set_tensor(dmel_convnext* m, const char* key, const
   DMEL_CHECK_ARG(m, "NULL handle");
   m->ready = false;
   return m->ts.set(key, data, shape, ndim);
+}
+extern "C" int dmel_convnext_set_train_precision(dmel_convnext* m, int precision) {
+  DMEL_CHECK_ARG(m && (precision == DMEL_PRECISION_FP32 || precision == DMEL_PRECISION_BF16), "convnext_set_train_precision: DMEL_PRECISION_FP32 or DMEL_PRECISION_BF16");
+  m->train_precision = precision;
+  return DMEL_OK;
 }
 extern "C" int dmel_convnext_enable_training(dmel_convnext* m, int on) {
   DMEL_CHECK_ARG(m, "NULL handle");
@@ -968,6 +982,7 @@ extern "C" int dmel_convnext_grad_slot(const dmel_convnext* m, const char* key, 
 
 extern "C" int dmel_convnext_forward_train(const dmel_convnext* m, const float* x, float* y, int N, int64_t T, void* workspace,
                                            size_t workspace_bytes, void* stream) {
+  TrainPrecisionScope train_scope(m ? m->train_precision : 0);
   DMEL_CHECK_ARG(m && x && y && workspace, "convnext_forward_train: NULL argument");
   if (!m->ready || !m->train_ready) { set_error("convnext_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG(N > 0 && T > 0, "convnext_forward_train: bad shape");
@@ -978,6 +993,7 @@ extern "C" int dmel_convnext_forward_train(const dmel_convnext* m, const float* 
 
 extern "C" int dmel_convnext_backward(const dmel_convnext* m, const float* x, const float* dy, float* dx, float* grads, int N, int64_t T,
                                       void* workspace, size_t workspace_bytes, void* stream) {
+  TrainPrecisionScope train_scope(m ? m->train_precision : 0);
   DMEL_CHECK_ARG(m && x && dy && dx && grads && workspace, "convnext_backward: NULL argument");
   if (!m->ready || !m->train_ready) { set_error("convnext_backward: enable_training + finalize first"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG(N > 0 && T > 0, "convnext_backward: bad shape");
@@ -994,6 +1010,7 @@ extern "C" int dmel_convnext_backward(const dmel_convnext* m, const float* x, co
 }
 
 struct dmel_quantizer {
+  int train_precision = 0;     // DMEL_PRECISION_BF16: bf16 training mode
   int dim, G, Cg, D, nf;
   int factors[4];
   int levels[4];
@@ -1155,6 +1172,11 @@ extern "C" int dmel_quantizer_finalize(dmel_quantizer* q) {
   return DMEL_OK;
 }
 
+extern "C" int dmel_quantizer_set_train_precision(dmel_quantizer* q, int precision) {
+  DMEL_CHECK_ARG(q && (precision == DMEL_PRECISION_FP32 || precision == DMEL_PRECISION_BF16), "quantizer_set_train_precision: DMEL_PRECISION_FP32 or DMEL_PRECISION_BF16");
+  q->train_precision = precision;
+  return DMEL_OK;
+}
 extern "C" int dmel_quantizer_enable_training(dmel_quantizer* q, int on) {
   DMEL_CHECK_ARG(q, "NULL handle");
   q->train = on != 0;
@@ -1393,6 +1415,7 @@ extern "C" int dmel_quantizer_grad_slot(const dmel_quantizer* q, const char* key
 // (left = diff / 2) exactly as dowmsample_fsq.py:113-120.
 extern "C" int dmel_quantizer_forward_train(const dmel_quantizer* q, const float* z, float* zq, int32_t* ids, float* latents, int B,
                                             int64_t T, void* workspace, size_t workspace_bytes, void* stream) {
+  TrainPrecisionScope train_scope(q ? q->train_precision : 0);
   DMEL_CHECK_ARG(q && z && zq && workspace, "quantizer_forward_train: NULL argument");
   if (!q->ready || !q->train_ready) { set_error("quantizer_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
   const QPlan p = q_plan(q, B, T, workspace);
@@ -1439,6 +1462,7 @@ extern "C" int dmel_quantizer_forward_train(const dmel_quantizer* q, const float
 
 extern "C" int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, const float* dzq, float* dz, float* grads, int B, int64_t T,
                                        void* workspace, size_t workspace_bytes, void* stream) {
+  TrainPrecisionScope train_scope(q ? q->train_precision : 0);
   DMEL_CHECK_ARG(q && z && dzq && dz && grads && workspace, "quantizer_backward: NULL argument");
   if (!q->ready || !q->train_ready) { set_error("quantizer_backward: enable_training + finalize first"); return DMEL_EMISSING; }
   const QPlan p = q_plan(q, B, T, workspace);
@@ -1527,6 +1551,7 @@ int64_t disc_out_w(const DLayer& l, int64_t W) { return (W + 2 * l.pw - l.kw) / 
 }  // namespace
 
 struct dmel_discriminator {
+  int train_precision = 0;     // DMEL_PRECISION_BF16: bf16 training mode
   TensorStore ts;
   bool ready = false, train = false, train_ready = false;
   DLayer layer[kDiscLayers];
@@ -1644,6 +1669,11 @@ extern "C" int dmel_discriminator_finalize(dmel_discriminator* d) {
   return DMEL_OK;
 }
 
+extern "C" int dmel_discriminator_set_train_precision(dmel_discriminator* d, int precision) {
+  DMEL_CHECK_ARG(d && (precision == DMEL_PRECISION_FP32 || precision == DMEL_PRECISION_BF16), "discriminator_set_train_precision: DMEL_PRECISION_FP32 or DMEL_PRECISION_BF16");
+  d->train_precision = precision;
+  return DMEL_OK;
+}
 extern "C" int dmel_discriminator_enable_training(dmel_discriminator* d, int on) {
   DMEL_CHECK_ARG(d, "NULL handle");
   d->train = on != 0;
@@ -1956,6 +1986,7 @@ extern "C" int dmel_discriminator_grad_slot(const dmel_discriminator* d, const c
 
 extern "C" int dmel_discriminator_forward_train(const dmel_discriminator* d, const float* x, float* y, int B, int H, int64_t W,
                                                 void* workspace, size_t workspace_bytes, void* stream) {
+  TrainPrecisionScope train_scope(d ? d->train_precision : 0);
   DMEL_CHECK_ARG(d && x && y && workspace, "discriminator_forward_train: NULL argument");
   if (!d->ready || !d->train_ready) { set_error("discriminator_forward_train: enable_training + finalize first"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG(disc_shape_ok(d, B, H, W), "discriminator_forward_train: bad shape");
@@ -1969,6 +2000,7 @@ extern "C" int dmel_discriminator_forward_train(const dmel_discriminator* d, con
 // dy (B, H, W_out) -> dx (B, H, W) (nullable) and the parameter gradients (bias, weight-norm g and v of every layer) in `grads`
 extern "C" int dmel_discriminator_backward(const dmel_discriminator* d, const float* dy, float* dx, float* grads, int B, int H, int64_t W,
                                            void* workspace, size_t workspace_bytes, void* stream) {
+  TrainPrecisionScope train_scope(d ? d->train_precision : 0);
   DMEL_CHECK_ARG(d && dy && grads && workspace, "discriminator_backward: NULL argument");
   if (!d->ready || !d->train_ready) { set_error("discriminator_backward: enable_training + finalize first"); return DMEL_EMISSING; }
   DMEL_CHECK_ARG(disc_shape_ok(d, B, H, W), "discriminator_backward: bad shape");

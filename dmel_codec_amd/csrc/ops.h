@@ -34,6 +34,8 @@ int launch_masked_copy(const float* x, float* y, const int64_t* len, int div, in
 // unfold: y[n][c][t] = xf[c][n*P + t] * (t < len[n / div]).
 int launch_fold(const float* x, float* xf, const int64_t* len, int div, int N, int C, int64_t T, int P, int64_t pitch, hipStream_t s);
 int launch_unfold(const float* xf, float* y, const int64_t* len, int div, int N, int C, int64_t T, int P, int64_t pitch, hipStream_t s);
+int launch_resample(const float* x, float* y, const float* bank_dev, int B, int64_t L, int64_t Lout, int down, int up, int width,
+                    hipStream_t s);
 int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* up_taps_host,
                     const float* down_taps_host, int logscale, int B, int C, int64_t T, hipStream_t s);
 

@@ -401,6 +401,50 @@ int launch_unfold(const float* xf, float* y, const int64_t* len, int div, int N,
   return DMEL_OK;
 }
 
+// ---- polyphase sinc resampling (torchaudio.functional.resample, the call of utils/spectrogram.py:122-123) ------------------------
+// y[b, n * up + p] = sum_k bank[p][k] * xpad[b, n * down + k],  xpad = x padded with `width` zeros on the left and width + down on the
+// right, k < kw = 2 * width + down.  One thread per output sample; the (up x kw) filter bank sits in LDS when it fits (16 kHz -> 24 kHz:
+// 3 x 16 taps; 44.1 -> 24 kHz: 80 x 171), the input window comes through L1 (neighbouring outputs share all but `down` samples).
+// HBM-bound: 4 bytes read per input + 4 written per output sample.
+constexpr int kResampleLdsFloats = 15 * 1024;
+__global__ __launch_bounds__(256) void resample_kernel(const float* __restrict__ x, float* __restrict__ y, const float* __restrict__ bank,
+                                                       int64_t L, int64_t Lout, int down, int up, int width, int kw, int bank_in_lds) {
+  extern __shared__ float bsm[];
+  if (bank_in_lds) {
+    for (int i = threadIdx.x; i < up * kw; i += 256) bsm[i] = bank[i];
+    __syncthreads();
+  }
+  const float* bk = bank_in_lds ? bsm : bank;
+  const int64_t o = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (o >= Lout) return;
+  const int b = blockIdx.y;
+  const int64_t n = o / up;
+  const int p = (int)(o - n * up);
+  const float* xb = x + (int64_t)b * L;
+  const float* w = bk + (int64_t)p * kw;
+  const int64_t s0 = n * down - width;
+  float acc = 0.f;
+  for (int k = 0; k < kw; ++k) {
+    const int64_t s = s0 + k;
+    const float v = (s >= 0 && s < L) ? xb[s] : 0.f;
+    acc = fmaf(w[k], v, acc);
+  }
+  y[(int64_t)b * Lout + o] = acc;
+}
+
+int launch_resample(const float* x, float* y, const float* bank_dev, int B, int64_t L, int64_t Lout, int down, int up, int width,
+                    hipStream_t s) {
+  const int kw = 2 * width + down;
+  const int in_lds = up * kw <= kResampleLdsFloats;
+  {
+    ProfScope ps("small", s, 0.0, 4.0 * (double)B * ((double)L + (double)Lout));
+    hipLaunchKernelGGL(resample_kernel, dim3((unsigned)((Lout + 255) / 256), (unsigned)B), dim3(256),
+                       in_lds ? (size_t)up * kw * sizeof(float) : 0, s, x, y, bank_dev, L, Lout, down, up, width, kw, in_lds);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
 // ---- conv_post: C -> 1 channel, k taps, zero "same" padding, then tanh | clamp   (bigvgan.py:386-391) -----------
 // One output row: a 32-row MFMA tile would be 97 % zeros, so this is a plain reduction over (channel, tap) -- HBM
 // bound (C*T*4 bytes read per item, each input row read once per workgroup through L1).
@@ -479,4 +523,12 @@ extern "C" int dmel_mask_add_quality_f32(float* z, const int64_t* lengths, const
   }
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
+}
+
+extern "C" int dmel_resample_f32(const float* x, float* y, const float* filter_bank_dev, int B, int64_t L, int64_t Lout, int orig_freq,
+                                 int new_freq, int width, void* stream) {
+  DMEL_CHECK_ARG(x && y && filter_bank_dev, "resample: NULL argument");
+  DMEL_CHECK_ARG(B > 0 && B <= 65535 && L > 0 && Lout > 0 && orig_freq > 0 && new_freq > 0 && width >= 0, "resample: bad shape");
+  DMEL_CHECK_ARG(Lout <= (L * new_freq + orig_freq - 1) / orig_freq, "resample: Lout exceeds ceil(new_freq * L / orig_freq)");
+  return dmel::launch_resample(x, y, filter_bank_dev, B, L, Lout, orig_freq, new_freq, width, (hipStream_t)stream);
 }

@@ -118,8 +118,8 @@ constexpr int kMaxMelW = 2304;   // non-zero mel weights (each FFT bin feeds at 
 template <int P>
 __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const float* __restrict__ audio,
                                                           int64_t row_stride, const int64_t* __restrict__ lengths,
-                                                          float* __restrict__ out, int64_t L, int64_t T, int hop,
-                                                          int pad, int n_mels, int n_melw) {
+                                                          float* __restrict__ out, float* __restrict__ linear, int64_t L, int64_t T,
+                                                          int hop, int pad, int n_mels, int n_melw) {
   constexpr int H = 64 * P, N = 128 * P, U = (P + 7) / 8, EX = P * 72, NR = P / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float smem_stft[];
   cf* buf_all = reinterpret_cast<cf*>(smem_stft);                 // [kWaves][EX]   exchange buffer, reused by every pass
@@ -249,10 +249,15 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
       }
     }
     wave_sync();
+    // ---- optional linear-magnitude output, frame-major (B, T, H + 1): one coalesced row per frame (multi-resolution STFT loss)
+    if (linear) {
+      float* lo = linear + ((int64_t)b * T + t) * (H + 1);
+      for (int k = lane; k <= H; k += 64) lo[k] = mg[k];
+    }
     // ---- mel: one lane per band, ascending-bin fma chain over the band's triangle (weights from LDS)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-      if (lane + 64 * q < n_mels) {
+      if (out && lane + 64 * q < n_mels) {
         const float* w = melw + mptr[q];
         const float* g = mg + mst[q];
         float acc = 0.f;
@@ -263,6 +268,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
     wave_sync();   // mg and A are rewritten by the next frame
   }
   __syncthreads();
+  if (!out) return;
   const int64_t n_valid = lengths ? lengths[b] / hop : T;
   float* o = out + (int64_t)b * n_mels * T;
   for (int idx = tid; idx < n_mels * kFramesPerWG; idx += 256) {
@@ -437,7 +443,13 @@ extern "C" int64_t dmel_stft_num_frames(const dmel_stft_plan* p, int64_t L) {
 
 extern "C" int dmel_stft_logmel_f32(const dmel_stft_plan* p, const float* audio, int64_t row_stride, const int64_t* lengths,
                                     float* out, int B, int64_t L, void* stream) {
-  DMEL_CHECK_ARG(p && audio && out, "NULL argument");
+  DMEL_CHECK_ARG(out, "NULL argument");
+  return dmel_stft_f32(p, audio, row_stride, lengths, out, nullptr, B, L, stream);
+}
+
+extern "C" int dmel_stft_f32(const dmel_stft_plan* p, const float* audio, int64_t row_stride, const int64_t* lengths, float* out,
+                             float* linear, int B, int64_t L, void* stream) {
+  DMEL_CHECK_ARG(p && audio && (out || linear), "NULL argument");
   DMEL_CHECK_ARG(B > 0 && B <= 65535, "batch %d out of range", B);
   DMEL_CHECK_ARG(L > p->pad, "clip length %lld must exceed the reflect pad %d", (long long)L, p->pad);
   DMEL_CHECK_ARG(row_stride >= L, "row stride smaller than L");
@@ -453,15 +465,15 @@ extern "C" int dmel_stft_logmel_f32(const dmel_stft_plan* p, const float* audio,
     switch (p->n_fft) {
       case 512:
         hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(256), stft_lds_bytes<4>(), s, tb, audio, row_stride, lengths, out,
-                           L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+                           linear, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
         break;
       case 1024:
         hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(256), stft_lds_bytes<8>(), s, tb, audio, row_stride, lengths, out,
-                           L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+                           linear, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
         break;
       default:
         hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(256), stft_lds_bytes<16>(), s, tb, audio, row_stride, lengths,
-                           out, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+                           out, linear, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
     }
   }
   DMEL_HIP(hipGetLastError());

@@ -75,6 +75,14 @@ class VQGAN(nn.Module):
             if m is not None:
                 m.set_precision(precision)
 
+    def set_train_precision(self, precision) -> None:
+        """"bf16": the training paths of encoder, quantiser, decoder and discriminator run their convolutions with bf16 operands and
+        fp32 accumulation (BASELINE config 3, "DDP bf16"; the trainer maps `precision: bf16-mixed` to this).  "fp32" (default) is the
+        parity configuration -- the reference's codec configs train with precision 32 (config/codec/dMel_example.yaml:9)."""
+        for m in (self.encoder, self.quantizer, self.decoder, self.discriminator):
+            if m is not None:
+                m.set_train_precision(precision)
+
     @property
     def device(self) -> torch.device:
         return self.quality_projection.weight.device

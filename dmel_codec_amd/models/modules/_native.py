@@ -19,6 +19,7 @@ class NativeModule(nn.Module):
     _finalize_symbol = ""
     _precision_symbol = ""   # modules whose convolutions have the opt-in bf16 mode name their dmel_*_set_precision here
     _refresh_symbol = ""     # modules that can re-pack their weight images from device tensors name their dmel_*_refresh here
+    _train_precision_symbol = ""   # trainable modules name their dmel_*_set_train_precision here (bf16 training mode)
 
     def __init__(self):
         super().__init__()
@@ -26,6 +27,7 @@ class NativeModule(nn.Module):
         self._handle_versions = None
         self._ws = _lib.Workspace()
         self._precision = 0
+        self._train_precision = 0
         self._generation = 0          # bumped whenever the native weight images change (rebuild or device-side re-pack)
         self._grad_sink = None        # armed by ddp.GradReducer for the duration of one backward pass
         self._pending_train = 0       # training forwards whose backward has not run yet
@@ -72,6 +74,9 @@ class NativeModule(nn.Module):
                 _lib.check(getattr(L, self._finalize_symbol)(h), f"{type(self).__name__}.finalize")
                 if self._precision:
                     _lib.check(getattr(L, self._precision_symbol)(h, self._precision), f"{type(self).__name__}.set_precision")
+                if self._train_precision:
+                    _lib.check(getattr(L, self._train_precision_symbol)(h, self._train_precision),
+                               f"{type(self).__name__}.set_train_precision")
             except Exception:
                 getattr(L, self._destroy_symbol)(h)
                 raise
@@ -136,6 +141,20 @@ class NativeModule(nn.Module):
         if self._handle is not None and self._precision_symbol:
             _lib.check(getattr(_lib.lib(), self._precision_symbol)(self._handle, self._precision),
                        f"{type(self).__name__}.set_precision")
+
+    def set_train_precision(self, precision) -> None:
+        """Training-time arithmetic of the native forward_train / backward: "fp32" (default, the parity path) or "bf16" -- convolution
+        operands rounded to bf16, fp32 accumulation, fp32 parameters / activations / gradients / optimiser (what Lightning's
+        `precision: bf16-mixed` does to the reference's convolutions; include/dmel_hip.h: dmel_*_set_train_precision)."""
+        table = {"fp32": 0, "float32": 0, torch.float32: 0, 0: 0, "32": 0, 32: 0, "bf16": 1, "bfloat16": 1, "bf16-mixed": 1, torch.bfloat16: 1, 1: 1}
+        if precision not in table:
+            raise ValueError(f"train precision must be 'fp32' or 'bf16', got {precision!r}")
+        if table[precision] and not self._train_precision_symbol:
+            raise NotImplementedError(f"{type(self).__name__} has no bf16 training mode")
+        self._train_precision = table[precision]
+        if self._handle is not None and self._train_precision_symbol:
+            _lib.check(getattr(_lib.lib(), self._train_precision_symbol)(self._handle, self._train_precision),
+                       f"{type(self).__name__}.set_train_precision")
 
     def _free_native(self):
         if getattr(self, "_handle", None) is not None and _lib._lib is not None:

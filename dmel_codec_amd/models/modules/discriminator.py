@@ -55,6 +55,7 @@ class Discriminator(NativeModule):
     _destroy_symbol = "dmel_discriminator_destroy"
     _set_symbol = "dmel_discriminator_set_tensor"
     _finalize_symbol = "dmel_discriminator_finalize"
+    _train_precision_symbol = "dmel_discriminator_set_train_precision"
     _refresh_symbol = "dmel_discriminator_refresh"
 
     def __init__(self):

@@ -92,6 +92,7 @@ class DownsampleFiniteScalarQuantize(NativeModule):
     _destroy_symbol = "dmel_quantizer_destroy"
     _set_symbol = "dmel_quantizer_set_tensor"
     _finalize_symbol = "dmel_quantizer_finalize"
+    _train_precision_symbol = "dmel_quantizer_set_train_precision"
     _refresh_symbol = "dmel_quantizer_refresh"
 
     def __init__(self, input_dim: int = 512, n_codebooks: int = 9, n_groups: int = 1, levels=(8, 5, 5, 5),

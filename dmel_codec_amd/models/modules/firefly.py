@@ -71,6 +71,7 @@ class ConvNeXtBlock(NativeModule):
     _destroy_symbol = "dmel_convnext_destroy"
     _set_symbol = "dmel_convnext_set_tensor"
     _finalize_symbol = "dmel_convnext_finalize"
+    _train_precision_symbol = "dmel_convnext_set_train_precision"
 
     def __init__(self, dim: int, drop_path: float = 0.0, layer_scale_init_value: float = 1e-6, mlp_ratio: float = 4.0,
                  kernel_size: int = 7, dilation: int = 1):

@@ -128,6 +128,7 @@ class WaveNet(NativeModule):
     _destroy_symbol = "dmel_wavenet_destroy"
     _set_symbol = "dmel_wavenet_set_tensor"
     _finalize_symbol = "dmel_wavenet_finalize"
+    _train_precision_symbol = "dmel_wavenet_set_train_precision"
     _precision_symbol = "dmel_wavenet_set_precision"
     _refresh_symbol = "dmel_wavenet_refresh"
 

@@ -245,6 +245,32 @@ def _(audio, lengths, sample_rate, n_fft, win_length, hop_length, n_mels, f_min,
     return audio.new_empty((audio.shape[0], n_mels, audio.shape[1] // hop_length), dtype=torch.float32)
 
 
+@torch.library.custom_op("dmel_hip::stft_magnitude", mutates_args=(), device_types="cuda")
+def stft_magnitude(audio: Tensor, n_fft: int, win_length: int, hop_length: int) -> Tensor:
+    """Linear STFT magnitudes with the reference's framing (reflect pad (n_fft - hop) / 2, periodic hann of win_length centred in
+    n_fft, center=False, sqrt(re^2 + im^2 + 1e-9); utils/spectrogram.py:58-76): audio (B, L) -> (B, L // hop, n_fft // 2 + 1),
+    frame-major.  Same kernel as stft_logmel with the mel stage skipped (dmel_stft_f32)."""
+    _lib.require_cuda(audio, "audio")
+    y = audio.float()
+    if y.ndim != 2:
+        raise ValueError(f"expected (B, L), got {tuple(y.shape)}")
+    if y.stride(-1) != 1:
+        y = y.contiguous()
+    B, Ls = y.shape
+    L = _lib.lib()
+    with torch.cuda.device(y.device):
+        plan = _stft_plan(y.device, 16000, n_fft, win_length, hop_length, 1, 0.0, 0.0)       # the mel tables are not used
+        T = L.dmel_stft_num_frames(plan, Ls)
+        out = torch.empty(B, T, n_fft // 2 + 1, dtype=torch.float32, device=y.device)
+        _lib.check(L.dmel_stft_f32(plan, y.data_ptr(), y.stride(0), None, None, out.data_ptr(), B, Ls, _lib.stream_ptr()), "stft_magnitude")
+    return out
+
+
+@stft_magnitude.register_fake
+def _(audio, n_fft, win_length, hop_length):
+    return audio.new_empty((audio.shape[0], audio.shape[1] // hop_length, n_fft // 2 + 1), dtype=torch.float32)
+
+
 # ----------------------------------------------------------------------------------------------------- module-level ops
 @torch.library.custom_op("dmel_hip::wavenet_forward", mutates_args=("workspace",), device_types="cuda")
 def wavenet_forward(handle: int, x: Tensor, condition: Optional[Tensor], in_lengths: Optional[Tensor], out_lengths: Optional[Tensor],

@@ -90,6 +90,9 @@ class LogMelSpectrogram(nn.Module):
     def forward(self, x: Tensor, return_linear: bool = False, sample_rate: int = None,
                 lengths: Optional[Tensor] = None) -> Tensor:
         if sample_rate is not None and sample_rate != self.sample_rate:
-            # spectrogram.py:122-123 resamples with torchaudio; no reference config passes sample_rate.
-            raise NotImplementedError("on-the-fly resampling is outside the built path (SURVEY.md 8f rank 4)")
+            # spectrogram.py:122-123: torchaudio.functional.resample(x, orig_freq=sample_rate, new_freq=self.sample_rate)
+            from .resample import resample
+            x = resample(x, orig_freq=sample_rate, new_freq=self.sample_rate)
+            if lengths is not None:
+                lengths = (lengths.to(torch.int64) * self.sample_rate + sample_rate - 1) // sample_rate
         return self.spectrogram(x, lengths=lengths)

@@ -75,6 +75,21 @@ int64_t dmel_stft_num_frames(const dmel_stft_plan* plan, int64_t L);
  * of codec_lit_modules.py:492-506 fused in). */
 int dmel_stft_logmel_f32(const dmel_stft_plan* plan, const float* audio, int64_t audio_row_stride,
                          const int64_t* lengths, float* out, int B, int64_t L, void* stream);
+/* The same launch with the linear magnitudes sqrt(re^2 + im^2 + 1e-9) (utils/spectrogram.py:76) as a second, optional output:
+ * linear (B, T, n_fft/2 + 1), frame-major so that every frame is one coalesced row; logmel_out may be NULL (then the mel stage is
+ * skipped).  Consumer: the multi-resolution STFT loss BASELINE.json's north_star names (absent from the reference). */
+int dmel_stft_f32(const dmel_stft_plan* plan, const float* audio, int64_t audio_row_stride, const int64_t* lengths,
+                  float* logmel_out /*nullable*/, float* linear_out /*nullable*/, int B, int64_t L, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Sample-rate conversion in front of the STFT    replaces torchaudio.functional.resample as called by
+ * LogMelSpectrogram.forward(x, sample_rate=...) (utils/spectrogram.py:122-123): polyphase windowed-sinc filter bank,
+ * y[b, n * new + p] = sum_k bank[p][k] * xpad[b, n * orig + k], orig_freq / new_freq already divided by their gcd, xpad = x with `width`
+ * zeros in front, kw = 2 * width + orig_freq taps per phase.  filter_bank_dev: (new_freq, kw) fp32 on the device (the caller builds it:
+ * it depends on torchaudio's rolloff / window choices, which are host-side policy); x (B, L), y (B, Lout), Lout <= ceil(new * L / orig).
+ * ---------------------------------------------------------------------------------------------- */
+int dmel_resample_f32(const float* x, float* y, const float* filter_bank_dev, int B, int64_t L, int64_t Lout, int orig_freq,
+                      int new_freq, int width, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Anti-aliased Snake / SnakeBeta           replaces fwd_cuda (anti_alias_activation_cuda.cu:212-246) and the
@@ -128,6 +143,12 @@ int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const float* con
  * (layout of each slot = the parameter's own layout).  dx / dcondition may be NULL when not needed.  Gradients are
  * fp32-grade regardless of the handle's precision. */
 int dmel_wavenet_enable_training(dmel_wavenet* m, int on);
+/* bf16 training mode (BASELINE config 3 "DDP bf16"; the reference switches dtype / Lightning precision, codec_lit_modules.py:52-56,
+ * config/lm/lm_config.yaml:1,83): DMEL_PRECISION_BF16 makes every convolution of forward_train / backward run with operands rounded to
+ * bf16 and fp32 accumulation -- forward, backward-data, and the weight gradients of rows of >= 256 samples (shorter rows keep the exact
+ * fp32 kernel) -- while parameters, activations in HBM, gradients and the optimiser stay fp32 (autocast semantics).  The same setter
+ * exists for the other three trainable handles.  Default DMEL_PRECISION_FP32 (the parity path). */
+int dmel_wavenet_set_train_precision(dmel_wavenet* m, int precision);
 /* Re-pack every weight image of a finalized handle from DEVICE tensors (after an optimiser step): keys / device_tensors
  * name the state-dict tensors (weights (Cout, Cin, k) and biases, contiguous fp32) as they currently live on the device.
  * Runs on `stream`, no host copy, no allocation; produces bit-identical images to set_tensor + finalize on the same values. */
@@ -177,6 +198,7 @@ int dmel_convnext_create(dmel_convnext** m, int dim);
 void dmel_convnext_destroy(dmel_convnext* m);
 int dmel_convnext_set_tensor(dmel_convnext* m, const char* key, const float* data_host, const int64_t* shape, int ndim);
 int dmel_convnext_enable_training(dmel_convnext* m, int on);
+int dmel_convnext_set_train_precision(dmel_convnext* h, int precision);   /* see dmel_wavenet_set_train_precision */
 int dmel_convnext_finalize(dmel_convnext* m);
 size_t dmel_convnext_workspace_bytes(const dmel_convnext* m, int N, int64_t T);
 int dmel_convnext_forward(const dmel_convnext* m, const float* x, float* y, int N, int64_t T, void* workspace, size_t workspace_bytes,
@@ -220,6 +242,7 @@ int dmel_quantizer_decode(const dmel_quantizer* q, const int32_t* ids, float* z,
  * points (enable_training before finalize; the workspace of forward_train is handed to backward unchanged; one flat gradient buffer
  * addressed through grad_slot with the state-dict keys).  dz is always produced. */
 int dmel_quantizer_enable_training(dmel_quantizer* q, int on);
+int dmel_quantizer_set_train_precision(dmel_quantizer* h, int precision);   /* see dmel_wavenet_set_train_precision */
 /* as dmel_wavenet_refresh: re-pack every weight image / parameter buffer from device tensors named by their state-dict keys */
 int dmel_quantizer_refresh(dmel_quantizer* q, int n, const char* const* keys, const float* const* device_tensors, void* stream);
 size_t dmel_quantizer_train_workspace_bytes(const dmel_quantizer* q, int B, int64_t T);
@@ -284,6 +307,7 @@ int dmel_discriminator_forward(const dmel_discriminator* d, const float* x, floa
  * backward returns dx (nullable) and the gradients of bias / weight-norm g (original0) / v (original1) of every layer in the flat
  * buffer (the chain through torch._weight_norm is applied here).  enable_training requires the weight-normed form of the weights. */
 int dmel_discriminator_enable_training(dmel_discriminator* d, int on);
+int dmel_discriminator_set_train_precision(dmel_discriminator* h, int precision);   /* see dmel_wavenet_set_train_precision */
 /* as dmel_wavenet_refresh (keys: blocks.{i}.bias, ...original0, ...original1); the weight-norm fold runs on the device */
 int dmel_discriminator_refresh(dmel_discriminator* d, int n, const char* const* keys, const float* const* device_tensors, void* stream);
 size_t dmel_discriminator_train_workspace_bytes(const dmel_discriminator* d, int B, int H, int64_t W);

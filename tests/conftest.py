@@ -48,3 +48,16 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def report(line: str) -> None:
+    """Numbers a passing test wants on record (ids that differ, near-tie counts, streaming work ratio): printed, and appended to
+    gpurun_out/parity_report.txt so that they come back from the GPU box (copied into profiles/ for the round)."""
+    print(line)
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_report.txt"), "a") as f:
+            f.write(line + "\n")
+    except OSError:
+        pass

@@ -11,7 +11,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_err
+from conftest import rel_err, report
 from oracle import ref_cpu
 
 pytestmark = pytest.mark.gpu
@@ -388,6 +388,7 @@ def test_codec_encode_ids_bit_exact(dev, n_mels, G, sr, L):
     assert ids.dtype == torch.int32 and ids.shape == ids_ref.shape == (3, G, (L // 256) // 4)
     assert torch.equal(ilens.cpu(), lens_ref)
     n_diff, n_bad, n_tie = near_tie_report(ids, ids_ref, pre_ref)
+    report(f"[ids] encode {n_mels} mel / {G} groups / {sr} Hz, 3 ragged clips: n_diff={n_diff} n_tie(2e-4)={n_tie} of {ids.numel()} ids")
     assert n_bad == 0, f"{n_bad} id mismatches away from rounding boundaries ({n_diff} total, {n_tie} near-ties)"
     assert n_diff <= n_tie
     assert int(ids.max()) < math.prod(cfg["levels"]) and int(ids.min()) >= 0
@@ -503,7 +504,7 @@ def test_incremental_decode_with_state_carry(dev, pattern):
     # latency in tokens: the first audio appears once WaveNet (75 frames) + vocoder (~20) + quantiser (16) context has arrived
     assert first_audio_after is not None and first_audio_after <= 64
     if pattern == "64":
-        print(f"[stream] conv flops streamed / whole = {streamed / whole:.3f}, first audio after {first_audio_after} tokens")
+        report(f"[stream] conv flops streamed / whole = {streamed / whole:.3f}, first audio after {first_audio_after} tokens")
         assert streamed <= 1.2 * whole, streamed / whole
     # the generator form over an arbitrary iterable of chunks
     parts = list(codec.decode_stream(iter([ids[:, :, :150], ids[:, :, 150:]]), flen, noise=None, return_audios=False))
