@@ -92,7 +92,15 @@ struct StftTables {
   const int* mel_cnt;   // [n_mels] number of bins
   const int* mel_ptr;   // [n_mels] offset into mel_w
   const float* mel_w;   // packed non-zero weights
+  // balanced mel stage: every band's bin range is cut into chunks of kMelChunk bins (weights zero-padded); chunk i belongs to lane
+  // i % 64, pass i / 64
+  const int* ch_k0;     // [64 * passes] first FFT bin of the chunk (clamped so that k0 + kMelChunk - 1 stays inside the magnitude row)
+  const float* ch_w;    // [64 * passes][kMelChunk] weights, zeros past the band's end and for unused chunks
+  const int* band_pbeg; // [n_mels] first chunk of the band
+  const int* band_pcnt; // [n_mels] number of chunks of the band
 };
+constexpr int kMelChunk = 8;
+constexpr int kMaxMelPasses = 6;   // <= 384 chunks per frame: 2050 non-zero weights / 8 + one partly filled chunk per band (128 bands)
 
 __device__ __forceinline__ int64_t reflect_index(int64_t s, int64_t L) {
   if (s < 0) s = -s;
@@ -119,13 +127,14 @@ template <int P>
 __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const float* __restrict__ audio,
                                                           int64_t row_stride, const int64_t* __restrict__ lengths,
                                                           float* __restrict__ out, float* __restrict__ linear, int64_t L, int64_t T,
-                                                          int hop, int pad, int n_mels, int n_melw) {
+                                                          int hop, int pad, int n_mels, int mel_passes) {
   constexpr int H = 64 * P, N = 128 * P, U = (P + 7) / 8, EX = P * 72, NR = P / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float smem_stft[];
   cf* buf_all = reinterpret_cast<cf*>(smem_stft);                 // [kWaves][EX]   exchange buffer, reused by every pass
   float* mag_all = smem_stft + 2 * kWaves * EX;                   // [kWaves][H+8]
-  float* melw = mag_all + kWaves * (H + 8);                       // [kMaxMelW]
-  float (*tile)[kFramesPerWG + 1] = reinterpret_cast<float (*)[kFramesPerWG + 1]>(melw + kMaxMelW);   // [kMaxMels][33]
+  float* chw = mag_all + kWaves * (H + 8);                        // [mel_passes * 64][kMelChunk] chunk weights (LDS sized per plan)
+  int* chk0 = reinterpret_cast<int*>(chw + mel_passes * 64 * kMelChunk);   // [mel_passes * 64] first bin of every chunk
+  float (*tile)[kFramesPerWG + 1] = reinterpret_cast<float (*)[kFramesPerWG + 1]>(chk0 + mel_passes * 64);   // [kMaxMels][33]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -134,7 +143,9 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
   const int64_t t0 = (int64_t)blockIdx.x * kFramesPerWG;
   const float* x = audio + (int64_t)b * row_stride;
 
-  for (int i = tid; i < n_melw; i += 256) melw[i] = tb.mel_w[i];
+  for (int i = tid; i < mel_passes * 64 * kMelChunk; i += 256) chw[i] = tb.ch_w[i];
+  for (int i = tid; i < mel_passes * 64; i += 256) chk0[i] = tb.ch_k0[i];
+  if (tid < kWaves * 7) mag_all[(tid / 7) * (H + 8) + H + 1 + tid % 7] = 0.f;   // pad bins: read (times a zero weight) by the last chunks
 
   // per-lane constants kept in registers across the wave's frames (window and pass-1 twiddles only while they fit)
   constexpr bool kRegTables = P <= 8;
@@ -150,20 +161,21 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
   for (int j = 0; j < 8; ++j) w2[j] = tb.tw2[8 * j + (lane & 7)];
 #pragma unroll
   for (int j = 0; j < NR; ++j) wr[j] = tb.twr[min(lane + 64 * j, H / 2)];
-  // the (up to two) mel bands of this lane
-  int mst[2], mcnt[2], mptr[2];
+  // mel stage, balanced: this lane's (up to three) chunks of <= chunk_len bins, and the (up to two) bands whose chunk sums it adds up.
+  // One lane per BAND walked up to ~80 bins on the widest bands while 63 lanes idled (the wave pays for its slowest lane): 90
+  // dependent iterations per frame; chunked, the wave does 3 x chunk_len + (chunks of the widest band) ~ 35.
+  int bbeg[2], bcnt[2];
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int m = lane + 64 * q;
     const bool has = m < n_mels;
-    mst[q] = has ? tb.mel_start[m] : 0;
-    mcnt[q] = has ? tb.mel_cnt[m] : 0;
-    mptr[q] = has ? tb.mel_ptr[m] : 0;
+    bbeg[q] = has ? tb.band_pbeg[m] : 0;
+    bcnt[q] = has ? tb.band_pcnt[m] : 0;
   }
   const int k1l = lane >> 3, l7 = lane & 7;
   cf* A = buf_all + wave * EX;
   float* mg = mag_all + wave * (H + 8);
-  __syncthreads();   // melw visible
+  __syncthreads();   // mel tables visible
 
   for (int fi = 0; fi < kFramesPerWave; ++fi) {
     const int f = wave * kFramesPerWave + fi;
@@ -254,15 +266,28 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
       float* lo = linear + ((int64_t)b * T + t) * (H + 1);
       for (int k = lane; k <= H; k += 64) lo[k] = mg[k];
     }
-    // ---- mel: one lane per band, ascending-bin fma chain over the band's triangle (weights from LDS)
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      if (out && lane + 64 * q < n_mels) {
-        const float* w = melw + mptr[q];
-        const float* g = mg + mst[q];
+    // ---- mel: chunk partial sums (ascending-bin fma chains, weights from LDS) into the free exchange buffer, then per band the
+    //      ascending sum of its chunks
+    if (out) {
+      float* part = reinterpret_cast<float*>(A);
+      for (int q = 0; q < mel_passes; ++q) {                // wave-uniform trip count; the eight products are straight-line code
+        const int c = lane + 64 * q;
+        const float* w = chw + c * kMelChunk;
+        const float* g = mg + chk0[c];
         float acc = 0.f;
-        for (int i = 0; i < mcnt[q]; ++i) acc = fmaf(w[i], g[i], acc);
-        tile[lane + 64 * q][f] = logf(fmaxf(acc, 1e-5f));
+#pragma unroll
+        for (int i = 0; i < kMelChunk; ++i) acc = fmaf(w[i], g[i], acc);
+        part[c] = acc;
+      }
+      wave_sync();
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        if (lane + 64 * q < n_mels) {
+          const float* pp = part + bbeg[q];
+          float acc = 0.f;
+          for (int i = 0; i < bcnt[q]; ++i) acc += pp[i];
+          tile[lane + 64 * q][f] = logf(fmaxf(acc, 1e-5f));
+        }
       }
     }
     wave_sync();   // mg and A are rewritten by the next frame
@@ -278,8 +303,9 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
   }
 }
 
-template <int P> static size_t stft_lds_bytes() {
-  return (size_t)(2 * kWaves * P * 72 + kWaves * (64 * P + 8) + kMaxMelW + kMaxMels * (kFramesPerWG + 1)) * sizeof(float);
+template <int P> static size_t stft_lds_bytes(int mel_passes = kMaxMelPasses) {
+  return (size_t)(2 * kWaves * P * 72 + kWaves * (64 * P + 8) + mel_passes * 64 * (kMelChunk + 1) + kMaxMels * (kFramesPerWG + 1)) *
+         sizeof(float);
 }
 
 }  // namespace dmel
@@ -290,8 +316,8 @@ struct dmel_stft_plan {
   int sample_rate, n_fft, win_length, hop, n_mels, pad;
   double f_min, f_max;
   std::vector<float> basis;  // dense (n_mels, 513), host copy
-  DevBuf winz, tw1, tw2, twr, mel_start, mel_cnt, mel_ptr, mel_w;
-  int n_melw = 0;
+  DevBuf winz, tw1, tw2, twr, mel_start, mel_cnt, mel_ptr, mel_w, ch_k0, ch_w, band_pbeg, band_pcnt;
+  int n_melw = 0, mel_passes = 1;
 };
 
 namespace {
@@ -405,7 +431,31 @@ extern "C" int dmel_stft_plan_create(dmel_stft_plan** out, int sample_rate, int 
     return DMEL_EUNSUPPORTED;
   }
   p->n_melw = (int)packed.size();
+  // chunk table of the balanced mel stage: every band cut into kMelChunk-bin chunks, weights zero-padded
+  std::vector<int> ck0, bpb(n_mels), bpc(n_mels);
+  std::vector<float> cw;
+  for (int m = 0; m < n_mels; ++m) {
+    bpb[m] = (int)ck0.size();
+    for (int o = 0; o < cnt[m]; o += kMelChunk) {
+      ck0.push_back(st[m] + o);
+      for (int i = 0; i < kMelChunk; ++i) cw.push_back(o + i < cnt[m] ? packed[(size_t)ptr[m] + o + i] : 0.f);
+    }
+    bpc[m] = (int)ck0.size() - bpb[m];
+  }
+  p->mel_passes = std::max(1, (int)((ck0.size() + 63) / 64));
+  if (p->mel_passes > kMaxMelPasses) {
+    set_error("stft_logmel: %zu mel chunks exceed the %d the kernel holds per frame", ck0.size(), 64 * kMaxMelPasses);
+    delete p;
+    return DMEL_EUNSUPPORTED;
+  }
+  ck0.resize((size_t)64 * p->mel_passes, 0);
+  cw.resize((size_t)64 * p->mel_passes * kMelChunk, 0.f);
   int rc = DMEL_OK;
+  if ((rc = p->ch_k0.upload(ck0.data(), ck0.size() * sizeof(int))) || (rc = p->ch_w.upload(cw.data(), cw.size() * sizeof(float))) ||
+      (rc = p->band_pbeg.upload(bpb.data(), bpb.size() * sizeof(int))) || (rc = p->band_pcnt.upload(bpc.data(), bpc.size() * sizeof(int)))) {
+    delete p;
+    return rc;
+  }
   if ((rc = p->winz.upload(winz.data(), winz.size() * sizeof(cf))) || (rc = p->tw1.upload(tw1.data(), tw1.size() * sizeof(cf))) ||
       (rc = p->tw2.upload(tw2.data(), tw2.size() * sizeof(cf))) || (rc = p->twr.upload(twr.data(), twr.size() * sizeof(cf))) ||
       (rc = p->mel_start.upload(st.data(), st.size() * sizeof(int))) || (rc = p->mel_cnt.upload(cnt.data(), cnt.size() * sizeof(int))) ||
@@ -457,23 +507,24 @@ extern "C" int dmel_stft_f32(const dmel_stft_plan* p, const float* audio, int64_
   const int64_t T = dmel_stft_num_frames(p, L);
   DMEL_CHECK_ARG(T > 0, "clip too short for one frame");
   StftTables tb{p->winz.as<cf>(), p->tw1.as<cf>(), p->tw2.as<cf>(), p->twr.as<cf>(), p->mel_start.as<int>(),
-                p->mel_cnt.as<int>(), p->mel_ptr.as<int>(), p->mel_w.as<float>()};
+                p->mel_cnt.as<int>(), p->mel_ptr.as<int>(), p->mel_w.as<float>(), p->ch_k0.as<int>(), p->ch_w.as<float>(),
+                p->band_pbeg.as<int>(), p->band_pcnt.as<int>()};
   dim3 grid((unsigned)((T + kFramesPerWG - 1) / kFramesPerWG), (unsigned)B);
   hipStream_t s = (hipStream_t)stream;
   {
     ProfScope ps("stft_logmel", s, 0.0, (double)B * (4.0 * (double)L + 4.0 * p->n_mels * (double)T));
     switch (p->n_fft) {
       case 512:
-        hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(256), stft_lds_bytes<4>(), s, tb, audio, row_stride, lengths, out,
-                           linear, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+        hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(256), stft_lds_bytes<4>(p->mel_passes), s, tb, audio, row_stride, lengths, out,
+                           linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
         break;
       case 1024:
-        hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(256), stft_lds_bytes<8>(), s, tb, audio, row_stride, lengths, out,
-                           linear, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+        hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(256), stft_lds_bytes<8>(p->mel_passes), s, tb, audio, row_stride, lengths, out,
+                           linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
         break;
       default:
-        hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(256), stft_lds_bytes<16>(), s, tb, audio, row_stride, lengths,
-                           out, linear, L, T, p->hop, p->pad, p->n_mels, p->n_melw);
+        hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(256), stft_lds_bytes<16>(p->mel_passes), s, tb, audio, row_stride, lengths,
+                           out, linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
     }
   }
   DMEL_HIP(hipGetLastError());
