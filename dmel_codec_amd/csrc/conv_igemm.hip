@@ -814,7 +814,8 @@ template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int til
 // one 32-row strip per wave (4: weights fetched once per block), short ones with the 96-column tile (less padding at
 // T = 92 / 736); 64-row problems on 64x128, 32-row problems on 32x256.
 static int pick_tile_bf16(int mtiles, int64_t T) {
-  static int forced = [] { const char* e = getenv("DMEL_CONV_TILE_BF16"); return e ? atoi(e) : -1; }();
+  const char* e = getenv("DMEL_CONV_TILE_BF16");        // per call: tools/ab_wavenet.py switches tiles inside one process
+  const int forced = e ? atoi(e) : -1;
   if (forced >= 0 && forced < 6) return forced;
   if (mtiles >= 4) return T > 2048 ? 4 : 1;
   if (mtiles >= 2) return 2;

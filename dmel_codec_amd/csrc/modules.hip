@@ -128,6 +128,7 @@ struct dmel_wavenet {
   struct GradSlot { std::string key; int64_t offset, numel; };
   std::vector<GradSlot> slots;
   int64_t grad_floats = 0;
+  WaveNetFused fused;          // whole-stack kernel for narrow unconditioned WaveNets on short items (the dMel encoder)
 };
 
 
@@ -326,6 +327,25 @@ extern "C" int dmel_wavenet_finalize(dmel_wavenet* m) {
     m->recipe(&m->out_proj, {"output_projection.conv.weight", C, 1, 0, 0}, {"", 0, 0, 0, 0}, "output_projection.conv.bias");
   }
   if (m->train) DMEL_TRY(wavenet_pack_training(m));
+  // whole-stack kernel (wavenet_fused.hip): narrow, unconditioned, no output projection, dilations <= 8
+  m->fused.ok = false;
+  if (C > 32 && C <= 80 && !m->Ccond && !m->has_out && (!m->has_in || m->Cin <= 16) && (m->cycle == 0 || m->cycle <= 4)) {
+    WaveNetFused& f = m->fused;
+    f.Cin = m->Cin; f.C = C; f.L = m->L; f.cycle = m->cycle; f.has_in = m->has_in ? 1 : 0;
+    f.skip_scale = (float)(1.0 / std::sqrt((double)m->L));
+    f.in_w = m->has_in ? m->in_proj.w48.p : nullptr;
+    f.in_b = m->has_in ? m->in_proj.bias.as<float>() : nullptr;
+    f.skip_w = m->skip_proj.w48.p; f.skip_b = m->skip_proj.bias.as<float>();
+    std::vector<const void*> tab((size_t)4 * m->L);
+    for (int i = 0; i < m->L; ++i) {
+      tab[i] = m->gate[i].w48.p;
+      tab[m->L + i] = m->gate[i].bias.p;
+      tab[2 * m->L + i] = m->resskip[i].w48.p;
+      tab[3 * m->L + i] = m->resskip[i].bias.p;
+    }
+    DMEL_TRY(f.table.upload(tab.data(), tab.size() * sizeof(void*)));
+    f.ok = true;
+  }
   m->ts.t.clear();
   m->ready = true;
   return DMEL_OK;
@@ -443,6 +463,11 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
   DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "wavenet_forward: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
   hipStream_t st = (hipStream_t)stream;
   const int C = m->C, div = group_repeat > 0 ? group_repeat : 1;
+  {  // DMEL_WAVENET_FUSED=0 keeps the layered path (A/B); read per call
+    const char* e = getenv("DMEL_WAVENET_FUSED");
+    if (m->fused.ok && T <= 96 && m->precision == DMEL_PRECISION_FP32 && !(e && e[0] == '0') && !getenv("DMEL_CONV_FP32_MFMA"))
+      return launch_wavenet_fused(m->fused, x, y, in_lengths, out_lengths, div, N, T, st);
+  }
   const FoldGeom fold = wavenet_fold(m, N, T);
   if (fold.on) return wavenet_forward_folded(m, fold, p, x, condition, y, N, T, in_lengths, out_lengths, div, st);
 

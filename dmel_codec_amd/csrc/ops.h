@@ -36,6 +36,20 @@ int launch_fold(const float* x, float* xf, const int64_t* len, int div, int N, i
 int launch_unfold(const float* xf, float* y, const int64_t* len, int div, int N, int C, int64_t T, int P, int64_t pitch, hipStream_t s);
 int launch_resample(const float* x, float* y, const float* bank_dev, int B, int64_t L, int64_t Lout, int down, int up, int width,
                     hipStream_t s);
+// Whole-WaveNet kernel for narrow unconditioned stacks on short items (wavenet_fused.hip): device pointers into the handle's existing
+// split-bf16 weight images and biases; `table` = device array [gate_w[L] | gate_b[L] | rs_w[L] | rs_b[L]] of pointers.
+struct WaveNetFused {
+  bool ok = false;
+  int Cin = 0, C = 0, L = 0, cycle = 0, has_in = 0;
+  float skip_scale = 1.f;
+  const void* in_w = nullptr;
+  const float* in_b = nullptr;
+  const void* skip_w = nullptr;
+  const float* skip_b = nullptr;
+  DevBuf table;
+};
+int launch_wavenet_fused(const WaveNetFused& f, const float* x, float* y, const int64_t* in_len, const int64_t* out_len, int len_div, int N,
+                         int64_t T, hipStream_t st);
 int launch_aa_snake(const float* x, float* y, const float* alpha, const float* beta, const float* up_taps_host,
                     const float* down_taps_host, int logscale, int B, int C, int64_t T, hipStream_t s);
 

@@ -209,3 +209,46 @@ def test_multi_resolution_stft_loss(dev):
     assert abs(float(sc) - float(sc_ref)) < 1e-4 * float(sc_ref) and abs(float(lm) - float(lm_ref)) < 1e-4 * float(lm_ref)
     z = MultiResolutionSTFTLoss()(target.to(dev), target.to(dev))
     assert float(z[0]) == 0.0 and float(z[1]) == 0.0
+
+
+@pytest.mark.parametrize("cfg", [dict(input_channels=10, residual_channels=70, residual_layers=20, T=93, N=24),
+                                 dict(input_channels=10, residual_channels=70, residual_layers=5, T=96, N=3),
+                                 dict(input_channels=8, residual_channels=64, residual_layers=6, T=62, N=5),
+                                 dict(input_channels=48, residual_channels=48, residual_layers=4, T=17, N=4),
+                                 dict(input_channels=10, residual_channels=70, residual_layers=3, T=1, N=2)])
+def test_whole_stack_wavenet_kernel_is_bit_identical_to_the_layered_path(dev, cfg):
+    """csrc/wavenet_fused.hip: the encoder-shaped WaveNet (narrow, unconditioned, T <= 96) in ONE launch with x resident in LDS.  Its
+    arithmetic is the layered path's term for term, so the outputs must be EQUAL bit for bit (the token ids cannot move), with masks,
+    ragged lengths and group_repeat; and within 1e-4 of the oracle like every other path."""
+    import os
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    cfg = dict(cfg)
+    T, N = cfg.pop("T"), cfg.pop("N")
+    torch.manual_seed(5)
+    m = WaveNet(dilation_cycle=4, **cfg)
+    randomise(m, 17)
+    sd = cpu_sd(m)
+    g = torch.Generator().manual_seed(T + N)
+    x = torch.randn(N, cfg["input_channels"], T, generator=g)
+    m = m.to(dev)
+    xd = x.to(dev)
+    from dmel_codec_amd import _lib
+    runs, launches = {}, {}
+    with torch.no_grad():                  # the inference path (with gradients enabled the mirror runs its training forward)
+        for fused in ("0", "1"):
+            os.environ["DMEL_WAVENET_FUSED"] = fused
+            _lib.prof_reset(); _lib.prof_enable(True)
+            runs[fused] = m(xd)
+            torch.cuda.synchronize()
+            launches[fused] = _lib.prof_read("conv_igemm")["launches"]
+            _lib.prof_enable(False); _lib.prof_reset()
+            if N % 3 == 0:
+                lens = torch.randint(1, T + 1, (N // 3,), generator=torch.Generator().manual_seed(1)).to(dev)
+                runs[fused + "m"] = m(xd, in_lengths=lens, out_lengths=lens, group_repeat=3)
+    os.environ.pop("DMEL_WAVENET_FUSED")
+    assert launches["1"] == 1 and launches["0"] > 2 * cfg["residual_layers"], launches      # one launch instead of 2 L + 2
+    assert torch.equal(runs["0"], runs["1"]), float((runs["0"] - runs["1"]).abs().max())
+    if "0m" in runs:
+        assert torch.equal(runs["0m"], runs["1m"])
+    ref = ref_cpu.wavenet_forward(sd, "", x, cfg["residual_layers"], 4)
+    assert rel_err(runs["1"], ref) < 1e-4

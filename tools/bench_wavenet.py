@@ -18,6 +18,7 @@ ap.add_argument("--reps", type=int, default=30)
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
+torch.set_grad_enabled(False)        # the inference path (with gradients enabled the mirrors run their training forward)
 C = 70 * args.groups
 if args.which == "dec":
     m = WaveNet(input_channels=C, output_channels=10 * args.groups, residual_channels=C, residual_layers=20, dilation_cycle=4,
