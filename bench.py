@@ -113,7 +113,7 @@ def cpu_baseline(codec, workload: str, seconds_per_clip: float, budget_s: float)
             "one_pass_audio_sec_per_sec_by_threads": {str(k): round(n * seconds_per_clip / v, 3) for k, v in calib.items()}}
 
 
-def committed_traffic():
+def committed_traffic(conv=None):
     """HBM bytes per launch of the dominant kernel from the PMC passes (rocprofv3 --pmc, separate runs, corrected as the MI355X guide
     prescribes).  bench.py cannot read hardware counters itself: the figure is the one committed with the profile it came from
     (profiles/pmc_traffic.json: {"bytes_per_launch": ..., "source": ...}); null when no such file travels with the repo."""
@@ -121,8 +121,11 @@ def committed_traffic():
     try:
         with open(path) as f:
             d = json.load(f)
-        return {"bytes_per_launch": d["bytes_per_launch"], "algorithmic_bytes_per_launch": d.get("algorithmic_bytes_per_launch"),
-                "source": d.get("source")}
+        alg = d.get("algorithmic_bytes_per_launch")
+        if conv is not None and conv.get("launches"):
+            alg = round(conv["bytes"] / conv["launches"])        # counted live by the library for exactly these launches
+        return {"bytes_per_launch": d["bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
+                "ratio": round(d["bytes_per_launch"] / alg, 3) if alg else None, "source": d.get("source")}
     except (OSError, KeyError, ValueError):
         return None
 
@@ -322,7 +325,7 @@ def main() -> None:
                        "vocoder_streams": args.streams},
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
-                         "frac": round(ach / peak, 4), "traffic": committed_traffic(),
+                         "frac": round(ach / peak, 4), "traffic": committed_traffic(conv),
                          "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launches_per_step": conv["launches"] // max(1, args.steps),
                          "avg_launch_us": round(1e3 * conv["ms"] / max(1, conv["launches"]), 2),

@@ -947,7 +947,16 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
                  "conv: one batch item of the output exceeds 32-bit offsets");
   ka.mtiles = pc.Mpad / 32;
   const double rows_real = (d.mode == EPI_LINEAR ? (double)d.C * d.phases : 2.0 * d.C);
-  ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, 0.0);
+  // algorithmic HBM bytes of the launch: every input row once, every output element once (+ the residual / running-sum / skip rows the
+  // epilogue reads), the split weight image once
+  double in_elems = 0.0;
+  for (int s = 0; s < d.nseg; ++s) in_elems += (double)d.seg[s].Cin * (double)std::min<int64_t>(r.seg[s].Tin, r.Tcols * d.seg[s].tstride + max_halo);
+  double out_elems;
+  if (d.mode == EPI_LINEAR) out_elems = (double)d.C * d.phases * (double)r.Tcols * (1.0 + (r.res ? 1.0 : 0.0) + (r.accumulate ? 1.0 : 0.0));
+  else if (d.mode == EPI_GATE) out_elems = (double)d.C * (double)r.Tcols;
+  else out_elems = (double)d.C * (double)r.Tcols * (r.skip_first ? 3.0 : 4.0);
+  const double alg_bytes = 4.0 * r.B * (in_elems + out_elems) + (double)pc.Mpad * pc.steps * kCK * 6.0;
+  ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, alg_bytes);
   static const int native_fp32 = [] { const char* e = getenv("DMEL_CONV_FP32_MFMA"); return e ? atoi(e) : 0; }();
   if (r.precision == DMEL_PRECISION_BF16 || train_precision_override() == DMEL_PRECISION_BF16)
     return launch_bf16_any<1>(ka, d.mode, r.B, r.Tcols, stream);

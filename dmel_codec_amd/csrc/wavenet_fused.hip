@@ -324,7 +324,8 @@ int launch_wavenet_fused(const WaveNetFused& f, const float* x, float* y, const 
   a.rs_b = reinterpret_cast<const float* const*>(reinterpret_cast<const char*>(f.table.p) + (size_t)3 * f.L * sizeof(void*));
   const int nch = (f.C + 15) / 16;
   double flops = 2.0 * N * (double)T * ((double)f.L * (2.0 * f.C * 3 * f.C + 2.0 * f.C * f.C) + (double)f.C * f.C + (f.has_in ? (double)f.C * f.Cin : 0.0));
-  ProfScope ps("conv_igemm", st, flops, 0.0);
+  const double wbytes = ((double)f.L * (2.0 * ((f.C + 15) / 16 * 16)) * (4.0 * ((f.C + 15) / 16 * 16)) + 2.0 * 96 * 96) * 6.0;
+  ProfScope ps("conv_igemm", st, flops, 4.0 * N * (double)T * (f.Cin + f.C) + wbytes);
   switch (nch) {
     case 5: return launch_fused_t<5>(a, st);
     case 4: return launch_fused_t<4>(a, st);

@@ -202,6 +202,15 @@ class WaveNet(NativeModule):
         if (condition is not None) != bool(self.condition_channels):
             raise ValueError("condition tensor does not match condition_channels")
         N, _, T = x.shape
+        if condition is not None:
+            # the C side receives raw pointers and (N, T) only: a mis-shaped or mis-placed condition would be read out of bounds
+            _lib.require_cuda(condition, "condition")
+            if condition.device != x.device:
+                raise ValueError(f"condition lives on {condition.device}, x on {x.device}")
+            if condition.shape != (N, self.condition_channels, T):
+                raise ValueError(f"condition must be {(N, self.condition_channels, T)}, got {tuple(condition.shape)}")
+        if any(p.device != x.device for _, p in self._trained_parameters()):
+            raise ValueError(f"WaveNet parameters and input live on different devices (input on {x.device})")
 
         def mask(v):
             v = v.reshape(-1).to(device=x.device, dtype=torch.int64)
