@@ -301,3 +301,28 @@ def test_two_data_parallel_ranks_of_the_real_training_step(dev):
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-8:])
     assert r.returncode == 0 and "PASS" in r.stdout, tail
     assert '"ranks_identical": true' in r.stdout
+
+
+def test_train_codec_under_torch_distributed_run_two_ranks(dev, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 train_codec.py ...` -- the launch line of INTEGRATION.md -- on this one GPU
+    (DMEL_TRAIN_SHARE_DEVICE=1 points both ranks at device 0, DMEL_DIST_BACKEND=gloo because RCCL wants one GPU per rank): trainer
+    process-group setup from the launcher's environment, per-rank data, gradient exchange, rank-mean of val_loss, rank-0 checkpoints
+    behind a barrier."""
+    import subprocess, sys
+    from conftest import ROOT
+    ck = str(tmp_path / "ckpt")
+    over = TINY + [f"codec_ckpt_dir={ck}", "trainer.max_steps=8", "trainer.val_check_interval=2", f"tensorboard_logger.save_dir={tmp_path / 'tb'}"]
+    env = dict(os.environ, DMEL_TRAIN_SHARE_DEVICE="1", DMEL_DIST_BACKEND="gloo")
+    torch.cuda.synchronize()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29500 + os.getpid() % 500), os.path.join(ROOT, "train_codec.py"), *over],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
+    assert r.returncode == 0, tail
+    assert "training_finished" in r.stdout and r.stdout.count("start_training") == 1, tail          # rank 0 speaks once
+    files = sorted(os.listdir(ck))
+    assert "last.ckpt" in files, files
+    ckpt = torch.load(os.path.join(ck, "last.ckpt"), map_location="cpu", weights_only=False)
+    assert ckpt["global_step"] == 8 and not any("vocoder" in k for k in ckpt["state_dict"])
+    lines = [l for l in open(tmp_path / "tb" / "dmel_codec_20hz" / "metrics.jsonl")]
+    assert any("val_loss" in l for l in lines)

@@ -1,6 +1,7 @@
 """Full VQGAN.training_step (codec_lit_modules.py:159-327: discriminator + generator steps, AdamW, schedulers, device-side weight
 re-pack) on the native training paths, BASELINE cfg-2/3 shapes.  GPU only.  Under `python -m torch.distributed.run --nproc-per-node N
-tools/bench_train_step.py` every rank trains on its own clips and the gradients are exchanged with RCCL (VQGAN.sync_gradients).
+tools/bench_train_step.py` every rank trains on its own clips and the gradients are exchanged with RCCL (dmel_codec_amd.ddp.GradReducer,
+overlapped with backward).  --precision bf16 selects the bf16 training mode.
 
     python tools/bench_train_step.py [--batch 32] [--seconds 1.0] [--steps 5]
 """
@@ -17,6 +18,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--seconds", type=float, default=1.0)
 ap.add_argument("--steps", type=int, default=5)
+ap.add_argument("--precision", default="fp32", choices=("fp32", "bf16"))
 args = ap.parse_args()
 world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
 torch.cuda.set_device(local)
@@ -30,6 +32,7 @@ opt = partial(torch.optim.AdamW, lr=1e-4, betas=(0.8, 0.99), eps=1e-5)          
 sched = partial(torch.optim.lr_scheduler.LambdaLR, lr_lambda=partial(get_cosine_schedule_with_warmup_lr_lambda, num_warmup_steps=100,
                                                                       num_training_steps=1000000, final_lr_ratio=0.0))
 codec = build_codec(n_mels=80, dmel_groups=8, vocoder=None, discriminator=True, optimizer=opt, lr_scheduler=sched).to(dev)
+codec.set_train_precision(args.precision)
 L = int(24000 * args.seconds)
 audio = bench.synth_audio(args.batch, L, 1234 + rank).to(dev)
 lens = torch.full((args.batch,), L, device=dev, dtype=torch.int64)
@@ -53,7 +56,7 @@ if rank == 0:
     n_d = sum(p.numel() for p in codec.discriminator.parameters())
     print(json.dumps({"workload": f"VQGAN.training_step, {world} rank(s) x {args.batch} x {args.seconds:g} s @24 kHz, 80 mel / 8 groups, WaveNet 20+20 "
                                   f"({n_g / 1e6:.1f} M) + discriminator ({n_d / 1e6:.1f} M)",
-                      "ms_per_step": round(el * 1e3, 2), "audio_sec_per_sec": round(world * args.batch * args.seconds / el, 1),
+                      "precision": args.precision, "ms_per_step": round(el * 1e3, 2), "audio_sec_per_sec": round(world * args.batch * args.seconds / el, 1),
                       "kernel_ms_one_step": fam, "losses": {k: round(v, 4) for k, v in logs.items()}}))
 if world > 1:
     dist.barrier()
