@@ -183,7 +183,8 @@ def test_activation1d_golden(dev, golden):
             assert rel_err(y, g.outs[f"y{t}"]) < 1e-5, (kind, t)
 
 
-@pytest.mark.parametrize("B,Cc,T", [(2, 5, 1023), (1, 3, 1024), (2, 2, 1025), (1, 4, 5000), (3, 32, 333)])
+@pytest.mark.parametrize("B,Cc,T", [(2, 5, 1023), (1, 3, 1024), (2, 2, 1025), (1, 4, 5000), (3, 32, 333), (2, 3, 1017), (1, 2, 1018), (2, 2, 1019),
+                                    (1, 3, 1024 + 6), (1, 2, 2036), (1, 2, 2037), (1, 3, 2044), (1, 2, 3)])
 def test_activation1d_tiles(dev, B, Cc, T):
     from dmel_codec_amd import _lib
     torch.manual_seed(T)
