@@ -36,6 +36,7 @@ class BigVGANConfig(C.Structure):
         ("activation_snake", C.c_int),
         ("use_tanh_at_final", C.c_int),
         ("use_bias_at_final", C.c_int),
+        ("resblock_type", C.c_int),
     ]
 
 

@@ -575,7 +575,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
   const int lb = b / a.len_div;
   // (Delaying the workgroups that land in odd wave slots -- so that a CU's two workgroups alternate between their MFMA loop and their
   // HBM-bound epilogue instead of doing both in phase -- was measured with 20 k / 50 k / 100 k cycle delays: 3-40 % slower on every
-  // shape.  The k = 3 layers' time is still close to MFMA time + epilogue traffic time, i.e. the two do not overlap.)
+  // shape when applied to every such workgroup, no gain beyond the +-10 % run-to-run noise when applied to the first round only.
+  // The k = 3 layers' time is still close to MFMA time + epilogue traffic time, i.e. the two do not overlap.)
 
   floatx16 acc[MT][NT];
 #pragma unroll

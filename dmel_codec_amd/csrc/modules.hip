@@ -2144,6 +2144,7 @@ extern "C" int dmel_bigvgan_create(dmel_bigvgan** out, const dmel_bigvgan_config
   DMEL_CHECK_ARG(cfg->num_upsamples >= 1 && cfg->num_upsamples <= 8 && cfg->num_kernels >= 1 && cfg->num_kernels <= 8,
                  "bigvgan: bad stage/kernel count");
   DMEL_CHECK_ARG(cfg->num_mels > 0 && cfg->upsample_initial_channel > 0, "bigvgan: bad channel counts");
+  DMEL_CHECK_ARG(cfg->resblock_type >= 0 && cfg->resblock_type <= 2, "bigvgan: resblock_type must be 1 (AMPBlock1) or 2 (AMPBlock2)");
   int64_t up = 1;
   for (int i = 0; i < cfg->num_upsamples; ++i) {
     const int u = cfg->upsample_rates[i], k = cfg->upsample_kernel_sizes[i];
@@ -2273,10 +2274,15 @@ extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
       const std::string bp = "resblocks." + std::to_string(i * c.num_kernels + j) + ".";
       for (int l = 0; l < 3; ++l) {
         ab.dil[l] = c.resblock_dilations[j][l];
-        DMEL_TRY(pack_same_conv(ab.c1[l], m->ts, bp + "convs1." + std::to_string(l) + ".", ch, ch, ab.k, ab.dil[l], true));
-        DMEL_TRY(pack_same_conv(ab.c2[l], m->ts, bp + "convs2." + std::to_string(l) + ".", ch, ch, ab.k, 1, true));
+        if (c.resblock_type == 2) {   // AMPBlock2: one dilated conv per layer (bigvgan.py:176-191), three activations
+          DMEL_TRY(pack_same_conv(ab.c1[l], m->ts, bp + "convs." + std::to_string(l) + ".", ch, ch, ab.k, ab.dil[l], true));
+        } else {
+          DMEL_TRY(pack_same_conv(ab.c1[l], m->ts, bp + "convs1." + std::to_string(l) + ".", ch, ch, ab.k, ab.dil[l], true));
+          DMEL_TRY(pack_same_conv(ab.c2[l], m->ts, bp + "convs2." + std::to_string(l) + ".", ch, ch, ab.k, 1, true));
+        }
       }
-      for (int a = 0; a < 6; ++a) DMEL_TRY(load_snake(ab.act[a], m->ts, bp + "activations." + std::to_string(a) + ".", ch, snake));
+      for (int a = 0; a < (c.resblock_type == 2 ? 3 : 6); ++a)
+        DMEL_TRY(load_snake(ab.act[a], m->ts, bp + "activations." + std::to_string(a) + ".", ch, snake));
     }
   }
   if (!m->ev_fork) {
@@ -2385,6 +2391,22 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
         // stagger the branches by one kernel: started together they run snake|snake|snake then conv|conv|conv in lockstep
         // and the VALU-bound activations never meet the matrix-pipe-bound convolutions on a CU
         if (l == 0 && multi && stagger && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_stag[j - 1], 0));
+        if (c.resblock_type == 2) {   // AMPBlock2.forward (bigvgan.py:232-237): xt = a(x); xt = c(xt); x = xt + x
+          DMEL_TRY(launch_aa_snake(xin, uj, ab.act[l].alpha.as<float>(), ab.act[l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
+          if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
+          ConvRun r2 = run_1seg(uj, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
+          r2.res = xin; r2.res_bs = bs; r2.res_cs = Tc;
+          if (l == 2) {
+            r2.accumulate = j > 0;
+            if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
+            if (multi && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
+          }
+          r2.precision = m->precision;
+          DMEL_TRY(launch_conv(ab.c1[l], r2, sj));
+          if (l == 2 && multi && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_chain[j], sj));
+          xin = xj;
+          continue;
+        }
         DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
         if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
         ConvRun r1 = run_1seg(uj, ch, Tc, vj, ch, Tc, B);

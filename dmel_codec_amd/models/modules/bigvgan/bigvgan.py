@@ -85,6 +85,28 @@ class AMPBlock1(nn.Module):
             l.fold()
 
 
+class AMPBlock2(nn.Module):
+    """bigvgan.py:150-241 (parameter container; forward runs inside dmel_bigvgan_forward): per dilation act -> conv -> + x."""
+
+    def __init__(self, h: AttrDict, channels: int, kernel_size: int = 3, dilation: tuple = (1, 3, 5), activation: str = None):
+        super().__init__()
+        self.h = h
+        self.kernel_size, self.dilation = kernel_size, tuple(dilation)
+        self.convs = nn.ModuleList([_wn_conv(channels, channels, kernel_size) for _ in dilation])
+        self.num_layers = len(self.convs)
+        if activation == "snake":
+            make = lambda: activations.Snake(channels, alpha_logscale=h.snake_logscale)
+        elif activation == "snakebeta":
+            make = lambda: activations.SnakeBeta(channels, alpha_logscale=h.snake_logscale)
+        else:
+            raise NotImplementedError("activation incorrectly specified. check the config file and look for 'activation'.")
+        self.activations = nn.ModuleList([Activation1d(activation=make()) for _ in range(self.num_layers)])
+
+    def remove_weight_norm(self):
+        for l in self.convs:
+            l.fold()
+
+
 class BigVGAN(NativeModule):
     """bigvgan.py:244-407."""
 
@@ -106,9 +128,11 @@ class BigVGAN(NativeModule):
         self.h["use_cuda_kernel"] = use_cuda_kernel
         self.num_kernels = len(h.resblock_kernel_sizes)
         self.num_upsamples = len(h.upsample_rates)
-        if h.resblock != "1":
-            if h.resblock == "2":
-                raise NotImplementedError("AMPBlock2 (resblock '2') is used by no shipped BigVGAN config and is not built")
+        if h.resblock == "1":                                   # bigvgan.py:303-311
+            resblock_class = AMPBlock1
+        elif h.resblock == "2":
+            resblock_class = AMPBlock2
+        else:
             raise ValueError(f"Incorrect resblock class specified in hyperparameters. Got {h.resblock}")
         c0 = h.upsample_initial_channel
         self.conv_pre = _wn_conv(h.num_mels, c0, 7, std=None)
@@ -120,7 +144,7 @@ class BigVGAN(NativeModule):
         for i in range(len(self.ups)):
             ch = c0 // (2 ** (i + 1))
             for k, d in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
-                self.resblocks.append(AMPBlock1(h, ch, k, d, activation=h.activation))
+                self.resblocks.append(resblock_class(h, ch, k, d, activation=h.activation))
         if h.activation == "snake":
             post = activations.Snake(ch, alpha_logscale=h.snake_logscale)
         elif h.activation == "snakebeta":
@@ -157,7 +181,7 @@ class BigVGAN(NativeModule):
         cfg.num_kernels = self.num_kernels
         for j, (k, d) in enumerate(zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes)):
             if len(d) != 3:
-                raise NotImplementedError("AMPBlock1 with other than 3 dilations")
+                raise NotImplementedError("AMP blocks with other than 3 dilations")
             cfg.resblock_kernel_sizes[j] = k
             for l in range(3):
                 cfg.resblock_dilations[j][l] = d[l]
@@ -165,6 +189,7 @@ class BigVGAN(NativeModule):
         cfg.activation_snake = int(h.activation == "snake")
         cfg.use_tanh_at_final = int(bool(self.use_tanh_at_final))
         cfg.use_bias_at_final = int(bool(self.use_bias_at_final))
+        cfg.resblock_type = 2 if h.resblock == "2" else 1
         handle = C.c_void_p()
         _lib.check(_lib.lib().dmel_bigvgan_create(C.byref(handle), C.byref(cfg)), "bigvgan_create")
         return handle.value
@@ -178,7 +203,10 @@ class BigVGAN(NativeModule):
         frames, rate = 3.0, 1
         widest = 0
         for k, dils in zip(h.resblock_kernel_sizes, h.resblock_dilation_sizes):
-            widest = max(widest, sum(12 + d * (k - 1) // 2 + (k - 1) // 2 for d in dils))
+            if h.resblock == "2":
+                widest = max(widest, sum(6 + d * (k - 1) // 2 for d in dils))
+            else:
+                widest = max(widest, sum(12 + d * (k - 1) // 2 + (k - 1) // 2 for d in dils))
         for u in h.upsample_rates:
             frames += 1.0 / rate
             rate *= u

@@ -258,7 +258,7 @@ int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, const float
 int dmel_mask_add_quality_f32(float* z, const int64_t* lengths, const float* w, const float* bias, float value,
                               int B, int C, int64_t T, void* stream);
 
-/* BigVGAN generator      replaces models/modules/bigvgan/bigvgan.py:367-393 (+ AMPBlock1 :132-141) */
+/* BigVGAN generator      replaces models/modules/bigvgan/bigvgan.py:367-393 (+ AMPBlock1 :132-141, AMPBlock2 :232-237) */
 typedef struct dmel_bigvgan dmel_bigvgan;
 typedef struct dmel_bigvgan_config {
   int num_mels;
@@ -273,6 +273,7 @@ typedef struct dmel_bigvgan_config {
   int activation_snake;    /* 1: "snake", 0: "snakebeta" */
   int use_tanh_at_final;
   int use_bias_at_final;
+  int resblock_type;       /* 1 (or 0): AMPBlock1 (bigvgan.py:31-147), 2: AMPBlock2 (bigvgan.py:150-241: per dilation act -> conv -> + x, keys convs.{l}) */
 } dmel_bigvgan_config;
 int dmel_bigvgan_create(dmel_bigvgan** m, const dmel_bigvgan_config* cfg);
 void dmel_bigvgan_destroy(dmel_bigvgan* m);

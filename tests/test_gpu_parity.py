@@ -295,6 +295,22 @@ def test_bigvgan_golden(dev, golden):
     assert rel_err(y, g.outs["audio"]) < TOL
 
 
+def test_bigvgan_ampblock2_golden(dev, golden):
+    """`resblock: "2"` (AMPBlock2, bigvgan.py:150-241): the HIP path against outputs of the reference's own class."""
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    from dmel_codec_amd.models.modules.bigvgan.env import AttrDict
+    g = golden("bigvgan_tiny_ampblock2")
+    m = BigVGAN(AttrDict(dict(g.meta["h"])))
+    m.load_state_dict(g.sd)
+    y = m.to(dev)(g.ins["mel"].to(dev))
+    assert y.shape == g.outs["audio"].shape
+    assert rel_err(y, g.outs["audio"]) < TOL
+    m.set_streams(1)
+    assert torch.equal(m(g.ins["mel"].to(dev)), y)           # one stream or three: same bits
+    m.remove_weight_norm()
+    assert rel_err(m(g.ins["mel"].to(dev)), g.outs["audio"]) < TOL
+
+
 def assert_close_to_truth(y, ref32, ref64, what=""):
     """Deep random-weight stacks amplify rounding noise: the fp32 oracle itself moves by 3-5e-5 relative when only
     its thread count (oneDNN blocking) changes.  So whole-network outputs are judged against the SAME oracle run in

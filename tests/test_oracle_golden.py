@@ -236,3 +236,18 @@ def test_strict_fsq_restatement():
         assert torch.equal(ref_cpu.fsq_prequant(sd_p, "", x[:, perm], levels, prebound, strict=True), s)
         far = ((a - a.floor() - 0.5).abs() > 1e-4).all(-1)
         assert torch.equal(ref_cpu.fsq_indices_from_prequant(a, levels)[far], ref_cpu.fsq_indices_from_prequant(s, levels)[far])
+
+
+def test_ampblock2_and_bigvgan_resblock2(golden):
+    """AMPBlock2 (`resblock: "2"`, bigvgan.py:150-241): the oracle against outputs of the reference's own classes."""
+    g = golden("ampblock2")
+    assert rel_err(ref_cpu.ampblock2(g.sd, "", g.ins["x"], g.meta["k"], g.meta["dilations"]), g.outs["y"]) < TOL
+    g = golden("bigvgan_tiny_ampblock2")
+    y = ref_cpu.bigvgan_forward(g.sd, g.meta["h"], g.ins["mel"])
+    assert y.shape == g.outs["audio"].shape and rel_err(y, g.outs["audio"]) < 5e-6
+    # the mirror's state-dict layout equals the reference's (keys and shapes)
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    from dmel_codec_amd.models.modules.bigvgan.env import AttrDict
+    m = BigVGAN(AttrDict(dict(g.meta["h"])))
+    sd = m.state_dict()
+    assert set(sd) == set(g.sd) and all(tuple(sd[k].shape) == tuple(g.sd[k].shape) for k in sd)
