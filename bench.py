@@ -199,9 +199,10 @@ def main() -> None:
                     help="extra steps timed one by one with events for the median / p10 / p90 of the step time (0 = skip)")
     ap.add_argument("--streams", type=int, default=3, choices=(1, 3),
                     help="streams BigVGAN's AMP blocks overlap on in the timed region (1 = serialised, for rocprofv3 runs)")
-    ap.add_argument("--decode-precision", default="fp32", choices=("fp32", "bf16"),
-                    help="fp32 (default, the parity path and the headline number) or the opt-in bf16-operand mode of the "
-                         "decode-side convolutions (never the default: it is outside the 1e-4 bar)")
+    ap.add_argument("--decode-precision", default="fp32", choices=("fp32", "fp32_bf16x3", "bf16"),
+                    help="fp32 (default, the parity path and the headline number: fp32-grade products, three-product fp16 split on the "
+                         "decode side), fp32_bf16x3 (six-product bf16 split everywhere: the round-1 arithmetic, for A/B) or the opt-in "
+                         "bf16-operand mode of the decode-side convolutions (never the default: it is outside the 1e-4 bar)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -297,15 +298,22 @@ def main() -> None:
         ach = conv["flops"] / (conv["ms"] * 1e-3) / 1e12 if conv["ms"] > 0 else 0.0
         bf16 = args.decode_precision == "bf16"
         native = os.environ.get("DMEL_CONV_FP32_MFMA", "0") not in ("", "0")
+        # Matrix-core ceiling of the family: every launch reports the flops it ISSUES for its algorithmic fp32 flops (6x under the three-way
+        # bf16 split: encoder, quantiser; 3x under the two-way fp16 split: decoder WaveNet, vocoder), so the ceiling
+        # for the step's ALGORITHMIC flops is the dense 16-bit MFMA peak divided by the flop-weighted mean of those factors.
+        factor = conv["issue_flops"] / conv["flops"] if conv["flops"] > 0 else 6.0
+        peak = PEAK_BF16_MFMA_TFLOPS / factor
         if bf16:
-            peak, kernel = PEAK_BF16_MFMA_TFLOPS, "conv_bf16_kernel<NP=1> (v_mfma_f32_32x32x16_bf16) + encoder-side fp32 convolutions"
+            kernel = "conv_bf16_kernel<NP=1> (v_mfma_f32_32x32x16_bf16) decode side + six-product split on the encoder side"
         elif native:
-            peak, kernel = PEAK_FP32_MFMA_TFLOPS, "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)"
+            kernel = "conv_igemm_kernel (fp32 v_mfma_f32_32x32x2_f32)"
+        elif args.decode_precision == "fp32_bf16x3":
+            kernel = ("conv_bf16_kernel<NP=3> (fp32 via exact 3-way bf16 operand split: 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 "
+                      "block, fp32 accumulate)")
         else:
-            # fp32 products from an exact 3-way bf16 split of both operands: 6 bf16 MFMAs per 32x32x16 block, so the
-            # ceiling for ALGORITHMIC fp32 flops is a sixth of the dense bf16 peak ("split fp32")
-            peak, kernel = PEAK_BF16_MFMA_TFLOPS / 6.0, ("conv_bf16_kernel<NP=3> (fp32 via exact 3-way bf16 operand split: "
-                                                        "6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 block, fp32 accumulate)")
+            kernel = ("conv_bf16_kernel<NP=2> on the decode side (fp32 via 2-way fp16 operand split, 2^-24 relative: 3 x "
+                      "v_mfma_f32_32x32x16_f16 per 32x32x16 block, two fp32 accumulators) + <NP=3> / wavenet_fused_kernel on the "
+                      "encode side (3-way bf16 split, 6 MFMAs per block: the ids are defined by it)")
         out = {
             "metric": "audio-sec/sec (encode+decode RTF) @24 kHz batch 32",
             "value": round(rate, 2),
@@ -326,6 +334,7 @@ def main() -> None:
             "roofline": {"bound": "mfma", "kernel": kernel,
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": committed_traffic(conv),
+                         "mfma_flops_issued_per_algorithmic_flop": round(factor, 3),
                          "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launches_per_step": conv["launches"] // max(1, args.steps),
                          "avg_launch_us": round(1e3 * conv["ms"] / max(1, conv["launches"]), 2),

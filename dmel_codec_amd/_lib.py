@@ -134,6 +134,7 @@ PROTOTYPES = {
     "dmel_prof_enable": (C.c_int, [C.c_int]),
     "dmel_prof_reset": (C.c_int, []),
     "dmel_prof_read": (C.c_int, [C.c_char_p, i64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "dmel_prof_read_ex": (C.c_int, [C.c_char_p, i64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
 }
 
 
@@ -205,6 +206,6 @@ def prof_reset() -> None:
 
 def prof_read(family: str):
     n = C.c_int64()
-    ms, fl, by = C.c_double(), C.c_double(), C.c_double()
-    check(lib().dmel_prof_read(family.encode(), C.byref(n), C.byref(ms), C.byref(fl), C.byref(by)), "prof_read")
-    return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value}
+    ms, fl, by, iss = C.c_double(), C.c_double(), C.c_double(), C.c_double()
+    check(lib().dmel_prof_read_ex(family.encode(), C.byref(n), C.byref(ms), C.byref(fl), C.byref(by), C.byref(iss)), "prof_read")
+    return {"launches": n.value, "ms": ms.value, "flops": fl.value, "bytes": by.value, "issue_flops": iss.value}

@@ -21,7 +21,7 @@ void set_error(const char* fmt, ...) {
 struct ProfRec {
   hipEvent_t start, stop;
   int family;
-  double flops, bytes;
+  double flops, bytes, issue;
 };
 struct ProfState {
   std::mutex mu;
@@ -34,7 +34,7 @@ static ProfState& prof() {
   return s;
 }
 
-ProfScope::ProfScope(const char* family, hipStream_t s, double flops, double bytes) : slot(-1), stream(s) {
+ProfScope::ProfScope(const char* family, hipStream_t s, double flops, double bytes, double issue_flops) : slot(-1), stream(s) {
   ProfState& p = prof();
   if (!p.on) return;
   std::lock_guard<std::mutex> lk(p.mu);
@@ -49,6 +49,7 @@ ProfScope::ProfScope(const char* family, hipStream_t s, double flops, double byt
   r.family = fam;
   r.flops = flops;
   r.bytes = bytes;
+  r.issue = issue_flops;
   if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess) return;
   (void)hipEventRecord(r.start, s);
   p.recs.push_back(r);
@@ -94,12 +95,12 @@ extern "C" int dmel_prof_reset(void) {
   return DMEL_OK;
 }
 
-extern "C" int dmel_prof_read(const char* family, int64_t* launches, double* total_ms, double* total_flops,
-                              double* total_bytes) {
+extern "C" int dmel_prof_read_ex(const char* family, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
+                                 double* total_issue_flops) {
   ProfState& p = prof();
   std::lock_guard<std::mutex> lk(p.mu);
   int64_t n = 0;
-  double ms = 0, fl = 0, by = 0;
+  double ms = 0, fl = 0, by = 0, is = 0;
   for (auto& r : p.recs) {
     if (p.families[r.family] != family) continue;
     if (hipEventSynchronize(r.stop) != hipSuccess) continue;
@@ -109,10 +110,16 @@ extern "C" int dmel_prof_read(const char* family, int64_t* launches, double* tot
     ms += t;
     fl += r.flops;
     by += r.bytes;
+    is += r.issue;
   }
   if (launches) *launches = n;
   if (total_ms) *total_ms = ms;
   if (total_flops) *total_flops = fl;
   if (total_bytes) *total_bytes = by;
+  if (total_issue_flops) *total_issue_flops = is;
   return DMEL_OK;
+}
+extern "C" int dmel_prof_read(const char* family, int64_t* launches, double* total_ms, double* total_flops,
+                              double* total_bytes) {
+  return dmel_prof_read_ex(family, launches, total_ms, total_flops, total_bytes, nullptr);
 }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -13,7 +14,49 @@
 
 namespace dmel {
 
-inline bool valid_precision(int p) { return p == DMEL_PRECISION_FP32 || p == DMEL_PRECISION_BF16 || p == DMEL_PRECISION_FP32_MFMA; }
+inline bool valid_precision(int p) { return p >= DMEL_PRECISION_FP32 && p <= DMEL_PRECISION_FP32_BF16X3; }
+// precision of a launch inside a training entry point / a backward pass: gradients span too many binades for the fp16 split, and the
+// bf16 inference mode is not a training mode (dmel_*_set_train_precision is)
+inline int exact_precision(int p) {
+  return (p == DMEL_PRECISION_BF16 || p == DMEL_PRECISION_FP32_F16X2 || p == DMEL_PRECISION_FP32_BF16X3) ? DMEL_PRECISION_FP32 : p;
+}
+
+// fp32 -> fp16 bits, round to nearest even, subnormals kept, overflow to inf: what v_cvt_f16_f32 does in the default mode (the host packer
+// and the device re-pack kernel must produce identical images)
+inline uint16_t f32_to_f16_bits(float f) {
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  const uint16_t sign = (uint16_t)((u >> 16) & 0x8000u);
+  const uint32_t a = u & 0x7fffffffu;
+  if (a > 0x7f800000u) return (uint16_t)(sign | 0x7e00u);                   // NaN
+  if (a >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                  // >= 65520 rounds to inf
+  if (a < 0x33000001u) return sign;                                         // <= 2^-25 rounds to zero (ties to even)
+  const int e = (int)(a >> 23) - 127;
+  uint32_t m = (a & 0x7fffffu) | 0x800000u;                                 // 24-bit significand
+  int shift = e >= -14 ? 13 : 13 + (-14 - e);                               // bits dropped
+  const uint32_t half = 1u << (shift - 1), mask = (1u << shift) - 1u;
+  uint32_t q = m >> shift;
+  const uint32_t rem = m & mask;
+  if (rem > half || (rem == half && (q & 1u))) ++q;
+  // normal: q in [2^10, 2^11]; exponent field e + 15, the implicit bit adds into it (a carry to 2^11 bumps the exponent)
+  const uint32_t bits = e >= -14 ? ((uint32_t)(e + 14) << 10) + q : q;
+  return (uint16_t)(sign | bits);
+}
+inline float f16_bits_to_f32(uint16_t h) {
+  const uint32_t sign = (uint32_t)(h & 0x8000u) << 16, e = (h >> 10) & 31u, m = h & 0x3ffu;
+  float f;
+  if (e == 0) f = std::ldexp((float)m, -24);
+  else if (e == 31) f = m ? NAN : INFINITY;
+  else f = std::ldexp((float)(m | 0x400u), (int)e - 25);
+  uint32_t u;
+  std::memcpy(&u, &f, 4);
+  u |= sign;
+  std::memcpy(&f, &u, 4);
+  return f;
+}
+constexpr float kF16XScale = 0.015625f;      // staged activations x 2^-6 ...
+constexpr float kF16WScale = 64.f;           // ... weight image x 2^6 (exact powers of two: the product is unchanged)
+constexpr float kF16LoScale = 2048.f;        // second piece is stored x 2^11
 
 
 void set_error(const char* fmt, ...);
@@ -72,7 +115,8 @@ struct DevBuf {
 
 // Per-family launch timing (bench.py's roofline leg): hipEvents on the launch stream.
 struct ProfScope {
-  ProfScope(const char* family, hipStream_t s, double flops, double bytes);
+  // issue_flops: matrix-core flops actually issued for `flops` algorithmic ones (x6 for the bf16 split, x3 for the fp16 split, ...)
+  ProfScope(const char* family, hipStream_t s, double flops, double bytes, double issue_flops = 0.0);
   ~ProfScope();
   int slot;
   hipStream_t stream;

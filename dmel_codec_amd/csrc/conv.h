@@ -34,6 +34,7 @@ struct PackedConv {
   DevBuf w, bias;
   DevBuf w16;              // the same weights rounded to bf16 (RNE), in 32x32x16 MFMA A-fragment order (DMEL_PRECISION_BF16)
   DevBuf w48;              // the same weights as three exact bf16 pieces (truncation split), same order (split-fp32 kernel)
+  DevBuf w32h;             // the same weights x 2^6 as two fp16 pieces (hi = fp16(w), lo = fp16((w - hi) 2^11)), same order (fp16-split kernel)
 };
 
 // Device-side re-pack (training: the weights change every optimiser step and live on the device).  A segment's source is an
@@ -160,6 +161,7 @@ template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, F
       return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);                    // round to nearest even
     };
     std::vector<uint16_t> w16((size_t)pc.Mpad * pc.steps * kCK, 0), w48((size_t)pc.Mpad * pc.steps * kCK * 3, 0);
+    std::vector<uint16_t> w32h((size_t)pc.Mpad * pc.steps * kCK * 2, 0);
     for (int m = 0; m < pc.Mpad; ++m) {
       int sr = src_row(m);
       if (sr < 0) continue;
@@ -182,11 +184,17 @@ template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, F
               w48[((base + 0) * 64 + lane) * 8 + j] = (uint16_t)(bits(p1) >> 16);
               w48[((base + 1) * 64 + lane) * 8 + j] = (uint16_t)(bits(p2) >> 16);
               w48[((base + 2) * 64 + lane) * 8 + j] = (uint16_t)(bits(r2) >> 16);
+              const float vs = v * kF16WScale;
+              const uint16_t hi = f32_to_f16_bits(vs);
+              const size_t bh = ((size_t)tile * pc.steps + step) * 2;
+              w32h[((bh + 0) * 64 + lane) * 8 + j] = hi;
+              w32h[((bh + 1) * 64 + lane) * 8 + j] = f32_to_f16_bits((vs - f16_bits_to_f32(hi)) * kF16LoScale);
             }
       }
     }
     DMEL_TRY(pc.w16.upload(w16.data(), w16.size() * sizeof(uint16_t)));
     DMEL_TRY(pc.w48.upload(w48.data(), w48.size() * sizeof(uint16_t)));
+    DMEL_TRY(pc.w32h.upload(w32h.data(), w32h.size() * sizeof(uint16_t)));
   }
   DMEL_TRY(pc.w.upload(w.data(), w.size() * sizeof(float)));
   DMEL_TRY(pc.bias.upload(b.data(), b.size() * sizeof(float)));

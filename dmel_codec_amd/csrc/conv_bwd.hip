@@ -471,7 +471,7 @@ extern "C" int dmel_conv_backward_data(dmel_conv* c, const float* dy, float* dx,
   ConvRun r;
   r.seg[0].x = dy; r.seg[0].bstride = (int64_t)c->Cout * T; r.seg[0].cstride = T; r.seg[0].Tin = T;
   r.B = B; r.Tcols = T; r.y = dx; r.y_bs = (int64_t)c->Cin * T; r.y_cs = T; r.Tout = T;
-  r.precision = c->precision == DMEL_PRECISION_BF16 ? DMEL_PRECISION_FP32 : c->precision;     // gradients stay fp32-grade
+  r.precision = exact_precision(c->precision);     // gradients stay on the exact split
   return launch_conv(c->pc_dgrad, r, (hipStream_t)stream);
 }
 

@@ -40,6 +40,7 @@ struct KArgs {
   const float* w;
   const void* w16;
   const void* w48;
+  const void* w32h;
   const float* bias;
   int64_t Tcols;
   int mode, act, C, RP, phases, out_tstride, phase_base, accumulate, len_div, skip_first;
@@ -536,6 +537,15 @@ template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KA
 //           fp32 rounding of the product itself, and far below the accumulation rounding of a K ~ 10^3 reduction.  Six
 //           32-cycle bf16 MFMAs per 32x32x16 block replace eight 64-cycle fp32 MFMAs: 2.67x less matrix-core time for the
 //           same fp32-grade result (tests: same error against the fp64 oracle as the fp32 MFMA kernel).
+//   NP = 2  "fp16 split" (DMEL_PRECISION_FP32_F16X2; the vocoder's default): every fp32 operand as TWO fp16 pieces, a = a_hi + 2^-11 a_lo
+//           with a_hi = fp16(a) and a_lo = fp16((a - a_hi) * 2^11), both round-to-nearest: |a - (a_hi + 2^-11 a_lo)| <= 2^-24 |a|, the unit
+//           roundoff of fp32.  THREE partial products per block (v_mfma_f32_32x32x16_f16): a_hi b_hi into `acc`, a_hi b_lo + a_lo b_hi
+//           into a second accumulator `acl` that is folded in once, acc + 2^-11 acl, before the epilogue; the dropped a_lo b_lo is
+//           below 2^-24 |ab|.  Same measured error against fp64 as NP = 3 and as an fp32 fma chain, half the matrix-core time of NP = 3.
+//           The second piece is kept SCALED so that it stays a normal fp16 number wherever the first one is; activations are staged
+//           x 2^-6 and the weight image carries 2^6 (exact), which centres the fp16 range on audio-network magnitudes: |x| < 4.19e6,
+//           absolute error 2^-30 below |x| = 2^-8.  Not used for gradients (too many binades) nor for the encoder (ids are defined
+//           by NP = 3).
 //   NP = 1  "bf16 operands" (DMEL_PRECISION_BF16, opt-in): operands rounded to bf16 (RNE), one MFMA per block.  This is the
 //           arithmetic the reference's LM configs ask for when they run the codec under dtype: bfloat16
 //           (config/lm/lm_config.yaml:1,83); it is outside the 1e-4 bar and never the default.
@@ -546,6 +556,8 @@ template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KA
 // step, straight from global/L2).  The x loads for chunk c+1 are issued at the first step of chunk c and land in LDS at its
 // last step, so their latency hides behind a whole chunk of MFMAs.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef DMEL_PD
 #define DMEL_PD 2   // weight prefetch distance in K steps
 #endif
@@ -557,7 +569,7 @@ __device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {      // {bf1
 // (amdgpu_waves_per_eu(2, 2) -- 166 VGPRs, accumulators out of the AGPRs -- was measured: 2-12 % slower on every bench shape, and the
 // allocator still parks one weight set on the B-fragment registers; the default register budget stays.)
 template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO, int NP, int KG>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs a) {
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_bf16_kernel(KArgs a) {
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NTHR = 64 * WAVES_M * WAVES_N;
   constexpr int XS = BN + HALO;
   constexpr int SUB = KG / 2;                            // 16-channel K steps (per tap) per staged chunk
@@ -585,6 +597,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+  // NP = 2: the cross terms a_hi b_lo + a_lo b_hi, 2^11 times their true size
+  floatx16 acl[NP == 2 ? MT : 1][NP == 2 ? NT : 1];
+  if constexpr (NP == 2) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acl[mi][ni][r] = 0.f;
+  }
 
   // Weight fragments: wave-uniform (scalar) base per row tile + a 16-byte lane offset, so a step's loads are
   // global_load_dwordx4 v, v_lane, s[base] offset:piece*1024 with one scalar add per step and no vector address math.
@@ -592,7 +614,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi) {
     const int tile = __builtin_amdgcn_readfirstlane(min(mblk * (BM / 32) + wave_m * MT + mi, a.mtiles - 1));
-    wT[mi] = reinterpret_cast<const char*>(NP == 3 ? a.w48 : a.w16) + (size_t)tile * a.steps * (NP * 1024);
+    wT[mi] = reinterpret_cast<const char*>(NP == 3 ? a.w48 : NP == 2 ? a.w32h : a.w16) + (size_t)tile * a.steps * (NP * 1024);
   }
   const uint32_t lane16 = lane * 16;
   auto load_w = [&](uint4 (&dst)[MT][NP], int step) {
@@ -636,7 +658,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
     }
   };
   auto store_x = [&](uint4* dst, int sg, int chunk) {
-    const float scale = a.seg[sg].in_scale;
+    const float scale = NP == 2 ? a.seg[sg].in_scale * kF16XScale : a.seg[sg].in_scale;
     const int Cin = a.seg[sg].Cin;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -651,6 +673,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
 #pragma unroll
         for (int e = 0; e < 8; ++e) p[e] = (__bf16)v[e];
         dst[i] = __builtin_bit_cast(uint4, p);
+      } else if constexpr (NP == 2) {
+        f16x8 ph, pl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const _Float16 hi = (_Float16)v[e];                       // v_cvt_f16_f32: round to nearest even, subnormals kept
+          ph[e] = hi;
+          pl[e] = (_Float16)((v[e] - (float)hi) * kF16LoScale);     // the subtraction is exact
+        }
+        dst[i] = __builtin_bit_cast(uint4, ph);
+        dst[PSZ + i] = __builtin_bit_cast(uint4, pl);
       } else {
         uint32_t p1[4], p2[4], p3[4];
 #pragma unroll
@@ -733,15 +765,28 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
       for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
         for (int p = 0; p < NP; ++p) bcur[ni][p] = __builtin_bit_cast(bf16x8, xp[p * PSZ + ni * 32]);
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
-#pragma unroll
-      for (int t = 0; t < (NP == 3 ? 6 : 1); ++t)
+      if constexpr (NP == 2) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use[mi][NP == 3 ? PA[t] : 0]),
-                                                                  bcur[ni][NP == 3 ? PB[t] : 0], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NT; ++ni) {
+            const f16x8 ah = __builtin_bit_cast(f16x8, use[mi][0]), al = __builtin_bit_cast(f16x8, use[mi][1]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, bcur[ni][0]), bl = __builtin_bit_cast(f16x8, bcur[ni][1]);
+            acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acl[mi][ni], 0, 0, 0);
+            acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acl[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mi][ni], 0, 0, 0);
+          }
+      } else {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+#pragma unroll
+        for (int t = 0; t < (NP == 3 ? 6 : 1); ++t)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, use[mi][NP == 3 ? PA[t] : 0]),
+                                                                    bcur[ni][NP == 3 ? PB[t] : 0], acc[mi][ni], 0, 0, 0);
+      }
     }
     __builtin_amdgcn_s_waitcnt(kWaitW);
     if (cstep == 0) {
@@ -771,6 +816,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void conv_bf16_kernel(KArgs
     if (UNR > 3 && s + 3 < a.steps) k_step(std::integral_constant<int, 3 % UNR>{}, s + 3);
     if (UNR > 4 && s + 4 < a.steps) k_step(std::integral_constant<int, 4 % UNR>{}, s + 4);
     if (UNR > 5 && s + 5 < a.steps) k_step(std::integral_constant<int, 5 % UNR>{}, s + 5);
+  }
+  if constexpr (NP == 2) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaf(acl[mi][ni][r], 1.f / kF16LoScale, acc[mi][ni][r]);
   }
   conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
 }
@@ -817,17 +870,19 @@ template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int til
 // Measured on MI355X (tools/bench_conv.py, DMEL_CONV_TILE_BF16 sweep): long rows of >= 128 output channels run best with
 // one 32-row strip per wave (4: weights fetched once per block), short ones with the 96-column tile (less padding at
 // T = 92 / 736); 64-row problems on 64x128, 32-row problems on 32x256.
-static int pick_tile_bf16(int mtiles, int64_t T) {
+// NP = 2 (two accumulator sets): the 96-column tile keeps 2-3 waves per SIMD where the 128-column one has 208 registers, and wins at every
+// length (bv2, 128 rows x 5888 columns: 176 / 233 / 250 TF/s against 117 / 182 / 206).
+static int pick_tile_bf16(int mtiles, int64_t T, int np) {
   const char* e = getenv("DMEL_CONV_TILE_BF16");        // per call: tools/ab_wavenet.py switches tiles inside one process
   const int forced = e ? atoi(e) : -1;
   if (forced >= 0 && forced < 6) return forced;
-  if (mtiles >= 4) return T > 2048 ? 4 : 1;
+  if (mtiles >= 4) return (T > 2048 && np != 2) ? 4 : 1;
   if (mtiles >= 2) return 2;
   return 3;
 }
 
 template <int NP> static int launch_bf16_any(const KArgs& ka, EpiMode mode, int B, int64_t Tcols, hipStream_t st) {
-  const int t16 = pick_tile_bf16(ka.mtiles, Tcols);
+  const int t16 = pick_tile_bf16(ka.mtiles, Tcols, NP);
   switch (mode) {
     case EPI_LINEAR: return launch_mode_bf16<EPI_LINEAR, NP>(ka, t16, B, st);
     case EPI_GATE: return launch_mode_bf16<EPI_GATE, NP>(ka, t16, B, st);
@@ -934,7 +989,7 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   }
   DMEL_CHECK_ARG(r.y != nullptr && r.B > 0 && r.Tcols > 0, "conv: bad output/batch/length");
   DMEL_CHECK_ARG(d.mode != EPI_RESSKIP || r.skip != nullptr, "conv: skip buffer missing");
-  ka.w = pc.w.as<float>(); ka.w16 = pc.w16.p; ka.w48 = pc.w48.p; ka.bias = pc.bias.as<float>();
+  ka.w = pc.w.as<float>(); ka.w16 = pc.w16.p; ka.w48 = pc.w48.p; ka.w32h = pc.w32h.p; ka.bias = pc.bias.as<float>();
   ka.Tcols = r.Tcols; ka.mode = d.mode; ka.act = r.act; ka.C = d.C; ka.RP = pc.RP; ka.phases = d.phases;
   ka.out_tstride = r.out_tstride; ka.phase_base = r.phase_base; ka.accumulate = r.accumulate;
   ka.len_div = r.len_div > 0 ? r.len_div : 1; ka.skip_first = r.skip_first; ka.out_div = r.out_div;
@@ -957,13 +1012,18 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   else if (d.mode == EPI_GATE) out_elems = (double)d.C * (double)r.Tcols;
   else out_elems = (double)d.C * (double)r.Tcols * (r.skip_first ? 3.0 : 4.0);
   const double alg_bytes = 4.0 * r.B * (in_elems + out_elems) + (double)pc.Mpad * pc.steps * kCK * 6.0;
-  ProfScope ps("conv_igemm", stream, 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real, alg_bytes);
   static const int native_fp32 = [] { const char* e = getenv("DMEL_CONV_FP32_MFMA"); return e ? atoi(e) : 0; }();
+  const bool one_piece = r.precision == DMEL_PRECISION_BF16 || train_precision_override() == DMEL_PRECISION_BF16;
+  const bool native = !one_piece && (native_fp32 || r.precision == DMEL_PRECISION_FP32_MFMA);
+  const double products = one_piece ? 1.0 : native ? 16.0 /* fp32 MFMA: 1/16 of the bf16 rate */ : r.precision == DMEL_PRECISION_FP32_F16X2 ? 3.0 : 6.0;
+  const double alg_flops = 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real;
+  ProfScope ps("conv_igemm", stream, alg_flops, alg_bytes, alg_flops * products);
   if (r.precision == DMEL_PRECISION_BF16 || train_precision_override() == DMEL_PRECISION_BF16)
     return launch_bf16_any<1>(ka, d.mode, r.B, r.Tcols, stream);
   // fp32: the split kernel is the default everywhere (after the wait-placement fixes it also wins on the 32-row, K < 128
   // layers of the last vocoder stage: 58 vs 72 us); the native fp32-MFMA kernels serve DMEL_PRECISION_FP32_MFMA
-  if (r.precision == DMEL_PRECISION_FP32 && !native_fp32)
+  if (r.precision == DMEL_PRECISION_FP32_F16X2 && !native_fp32) return launch_bf16_any<2>(ka, d.mode, r.B, r.Tcols, stream);
+  if ((r.precision == DMEL_PRECISION_FP32 || r.precision == DMEL_PRECISION_FP32_BF16X3 || r.precision == DMEL_PRECISION_FP32_F16X2) && !native_fp32)
     return launch_bf16_any<3>(ka, d.mode, r.B, r.Tcols, stream);
   const int tile = pick_tile(ka.mtiles, r.Tcols, r.B);
   switch (d.mode) {

@@ -610,7 +610,7 @@ TrainPlan train_plan(const dmel_wavenet* m, int N, int64_t T, void* ws) {
   p.bytes = align_up(a.off, 256);
   return p;
 }
-int train_precision(const dmel_wavenet* m) { return m->precision == DMEL_PRECISION_BF16 ? DMEL_PRECISION_FP32 : m->precision; }
+int train_precision(const dmel_wavenet* m) { return exact_precision(m->precision); }
 }  // namespace
 
 extern "C" int dmel_wavenet_refresh(dmel_wavenet* m, int n, const char* const* keys, const float* const* device_tensors,
@@ -2353,13 +2353,17 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
   DMEL_CHECK_ARG(workspace_bytes >= need, "bigvgan_forward: workspace too small (%zu < %zu)", workspace_bytes, need);
   hipStream_t st = (hipStream_t)stream;
   const dmel_bigvgan_config& c = m->cfg;
+  // "fp32-grade, library's choice": nothing downstream of the vocoder is discrete, so its default is the three-product fp16 split
+  // (include/dmel_hip.h); DMEL_VOCODER_F16X2=0 is the A/B switch back to the six-product bf16 split
+  const char* f16_env = getenv("DMEL_VOCODER_F16X2");
+  const int prec = m->precision == DMEL_PRECISION_FP32 && !(f16_env && f16_env[0] == '0') ? DMEL_PRECISION_FP32_F16X2 : m->precision;
   const int logscale = c.snake_logscale;
   float *x = bufs[0], *xu = bufs[1], *xs = bufs[2];
   float* ua = bufs[4];   // block 0's activation scratch doubles as the post-activation buffer
 
   {  // conv_pre (bigvgan.py:369)
     ConvRun r = run_1seg(mel, c.num_mels, T, x, c.upsample_initial_channel, T, B);
-    r.precision = m->precision;
+    r.precision = prec;
     DMEL_TRY(launch_conv(m->conv_pre, r, st));
   }
   int64_t Tc = T;
@@ -2370,7 +2374,7 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
     for (int half = 0; half < 2; ++half) {  // transposed conv as two phase groups (bigvgan.py:371-374)
       ConvRun r = run_1seg(x, us.Cin, Tc, xu, us.Cout, Tn, B);
       r.Tcols = Tc; r.out_tstride = us.u; r.phase_base = half * (us.u / 2); r.Tout = Tn;
-      r.precision = m->precision;
+      r.precision = prec;
     DMEL_TRY(launch_conv(half == 0 ? us.lo : us.hi, r, st));
     }
     ch = us.Cout;
@@ -2401,7 +2405,7 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
             if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
             if (multi && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           }
-          r2.precision = m->precision;
+          r2.precision = prec;
           DMEL_TRY(launch_conv(ab.c1[l], r2, sj));
           if (l == 2 && multi && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_chain[j], sj));
           xin = xj;
@@ -2410,7 +2414,7 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
         DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
         if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
         ConvRun r1 = run_1seg(uj, ch, Tc, vj, ch, Tc, B);
-        r1.precision = m->precision;
+        r1.precision = prec;
     DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
         DMEL_TRY(launch_aa_snake(vj, uj, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
         ConvRun r2 = run_1seg(uj, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
@@ -2421,7 +2425,7 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
           if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
           if (multi && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
         }
-        r2.precision = m->precision;
+        r2.precision = prec;
     DMEL_TRY(launch_conv(ab.c2[l], r2, sj));
         if (l == 2 && multi && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_chain[j], sj));
         xin = xj;

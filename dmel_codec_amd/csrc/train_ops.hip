@@ -237,6 +237,7 @@ struct RepackArgs {
   float* w;
   uint16_t* w16;
   uint16_t* w48;
+  uint16_t* w32h;
   float* bias;
   int mode, C, RP, phases, nseg, Mpad, steps;
   int Cin[2], taps[2], nchunk[2];
@@ -289,6 +290,13 @@ __global__ void repack_kernel(RepackArgs a) {
       a.w48[((base + 0) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(p1) >> 16);
       a.w48[((base + 1) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(p2) >> 16);
       a.w48[((base + 2) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(r2) >> 16);
+      // fp16 pieces of 2^6 w (conv.h pack_conv; v_cvt_f16_f32 rounds to nearest even and keeps subnormals, like f32_to_f16_bits)
+      const float vs = v * kF16WScale;
+      const _Float16 hi = (_Float16)vs;
+      const _Float16 lo = (_Float16)((vs - (float)hi) * kF16LoScale);
+      const int64_t bh = ((int64_t)tile * a.steps + step) * 2;
+      a.w32h[((bh + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, hi);
+      a.w32h[((bh + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, lo);
     }
     if (step == 0 && k == 0) {
       float b = 0.f;
@@ -304,12 +312,12 @@ __global__ void repack_kernel(RepackArgs a) {
 
 int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t s) {
   const PackDesc& d = pc.d;
-  DMEL_CHECK_ARG(pc.w.p && pc.w16.p && pc.w48.p && pc.bias.p, "repack: the convolution was never packed");
+  DMEL_CHECK_ARG(pc.w.p && pc.w16.p && pc.w48.p && pc.w32h.p && pc.bias.p, "repack: the convolution was never packed");
   DMEL_CHECK_ARG(d.nseg >= 1 && d.nseg <= 2 && src.seg[0].w && (d.nseg == 1 || src.seg[1].w), "repack: missing source tensor");
   RepackArgs a{};
   a.seg[0] = src.seg[0]; a.seg[1] = src.seg[1];
   a.b0 = src.b0; a.b1 = src.b1; a.bias_mod = src.bias_mod;
-  a.w = pc.w.as<float>(); a.w16 = pc.w16.as<uint16_t>(); a.w48 = pc.w48.as<uint16_t>(); a.bias = pc.bias.as<float>();
+  a.w = pc.w.as<float>(); a.w16 = pc.w16.as<uint16_t>(); a.w48 = pc.w48.as<uint16_t>(); a.w32h = pc.w32h.as<uint16_t>(); a.bias = pc.bias.as<float>();
   a.mode = d.mode; a.C = d.C; a.RP = pc.RP; a.phases = d.phases; a.nseg = d.nseg; a.Mpad = pc.Mpad; a.steps = pc.steps;
   for (int i = 0; i < d.nseg; ++i) {
     a.Cin[i] = d.seg[i].Cin; a.taps[i] = d.seg[i].taps; a.nchunk[i] = (d.seg[i].Cin + kCK - 1) / kCK;

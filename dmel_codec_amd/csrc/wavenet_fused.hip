@@ -325,7 +325,7 @@ int launch_wavenet_fused(const WaveNetFused& f, const float* x, float* y, const 
   const int nch = (f.C + 15) / 16;
   double flops = 2.0 * N * (double)T * ((double)f.L * (2.0 * f.C * 3 * f.C + 2.0 * f.C * f.C) + (double)f.C * f.C + (f.has_in ? (double)f.C * f.Cin : 0.0));
   const double wbytes = ((double)f.L * (2.0 * ((f.C + 15) / 16 * 16)) * (4.0 * ((f.C + 15) / 16 * 16)) + 2.0 * 96 * 96) * 6.0;
-  ProfScope ps("conv_igemm", st, flops, 4.0 * N * (double)T * (f.Cin + f.C) + wbytes);
+  ProfScope ps("conv_igemm", st, flops, 4.0 * N * (double)T * (f.Cin + f.C) + wbytes, 6.0 * flops);
   switch (nch) {
     case 5: return launch_fused_t<5>(a, st);
     case 4: return launch_fused_t<4>(a, st);

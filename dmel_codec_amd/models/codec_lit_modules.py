@@ -66,14 +66,19 @@ class VQGAN(nn.Module):
         self.accumulate_grad = accumulate_grad
         if dmel_groups <= 0:
             raise NotImplementedError("only the dMel layout (dmel_groups > 0) works in the reference (SURVEY.md App. C)")
+        self.set_decode_precision("fp32")
 
     def set_decode_precision(self, precision) -> None:
-        """Opt-in throughput mode for decode(): "bf16" runs the decoder WaveNet and the vocoder convolutions with
-        bf16-rounded operands and fp32 accumulation (tensors stay fp32); "fp32" (default) is the parity path.
-        encode() is not affected: the ids are the interchange format and stay bit-stable."""
+        """Arithmetic of decode()'s convolutions (decoder WaveNet + vocoder; tensors stay fp32).  "fp32" (default) is the parity path:
+        fp32-grade products from the three-product fp16 split (include/dmel_hip.h, DMEL_PRECISION_FP32_F16X2 -- same error against an
+        fp64 evaluation as an fp32 fma chain); "fp32_bf16x3" forces the six-product bf16 split there too; "bf16" is the opt-in
+        throughput mode with bf16-rounded operands.  encode() is not affected: the ids are the interchange format and stay bit-stable
+        (encoder and quantiser always run the six-product split)."""
+        self._decode_precision = precision
         for m in (self.decoder, self.vocoder):
             if m is not None:
-                m.set_precision(precision)
+                # the decoder WaveNet handle's own "fp32" means the six-product split (an encoder is a WaveNet too): ask for the fp16 one
+                m.set_precision("fp32_f16x2" if precision in ("fp32", "float32", torch.float32, 0) and m is self.decoder else precision)
 
     def set_train_precision(self, precision) -> None:
         """"bf16": the training paths of encoder, quantiser, decoder and discriminator run their convolutions with bf16 operands and

@@ -128,13 +128,14 @@ class NativeModule(nn.Module):
                 and all(p.grad is None for p in params))
 
     def set_precision(self, precision) -> None:
-        """"fp32" (default; the parity path), "fp32_mfma" (force the native fp32 MFMA kernel) or "bf16": convolution operands
-        rounded to bf16, fp32 accumulation, fp32 tensors everywhere else (include/dmel_hip.h, DMEL_PRECISION_*).  Accepts the
-        strings, torch dtypes or the DMEL_PRECISION_* integers."""
+        """"fp32" (default; the parity path: fp32-grade products, the library picks the construction), "fp32_f16x2" (force the
+        three-product fp16 split), "fp32_bf16x3" (force the six-product bf16 split), "fp32_mfma" (force the native fp32 MFMA kernel) or
+        "bf16": convolution operands rounded to bf16, fp32 accumulation, fp32 tensors everywhere else (include/dmel_hip.h,
+        DMEL_PRECISION_*).  Accepts the strings, torch dtypes or the DMEL_PRECISION_* integers."""
         table = {"fp32": 0, "float32": 0, torch.float32: 0, 0: 0, "bf16": 1, "bfloat16": 1, torch.bfloat16: 1, 1: 1,
-                 "fp32_mfma": 2, 2: 2}
+                 "fp32_mfma": 2, 2: 2, "fp32_f16x2": 3, 3: 3, "fp32_bf16x3": 4, 4: 4}
         if precision not in table:
-            raise ValueError(f"precision must be 'fp32', 'fp32_mfma' or 'bf16', got {precision!r}")
+            raise ValueError(f"precision must be 'fp32', 'fp32_f16x2', 'fp32_bf16x3', 'fp32_mfma' or 'bf16', got {precision!r}")
         if table[precision] and not self._precision_symbol:
             raise NotImplementedError(f"{type(self).__name__} has no bf16 mode")
         self._precision = table[precision]

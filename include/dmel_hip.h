@@ -38,6 +38,16 @@ extern "C" {
  *      both operands on the bf16 matrix cores (six partial products, dropped terms < 2^-21 relative; DESIGN.md "split
  *      fp32") -- both meet the same error bound against an fp64 evaluation and tests hold them to it.
  *  FP32_MFMA: force the native v_mfma_f32_32x32x2_f32 kernel (every product one exact fp32 fma).
+ *  FP32_F16X2: fp32-grade products from a TWO-way fp16 split of both operands (a = a_hi + 2^-11 a_lo, a_hi = fp16(a) round to nearest,
+ *      a_lo = fp16((a - a_hi) 2^11): 2^-24 relative, the unit roundoff of fp32 itself) and THREE partial products on the fp16 matrix
+ *      cores (a_hi b_hi into one fp32 accumulator, a_hi b_lo + a_lo b_hi into a second one that is folded in with 2^-11 at the end; the
+ *      dropped a_lo b_lo is < 2^-24 |ab|): the "3xTF32" construction with fp16 pieces -- half the matrix-core time of the six-product
+ *      bf16 split for the same error against an fp64 evaluation (tests hold both to the same bound).  Inputs are staged as x 2^-6 and
+ *      the weight image carries 2^6, so the fp16 range covers |x| < 4.19e6 (larger magnitudes overflow to inf -- loudly) and values
+ *      below 2^-8 keep an ABSOLUTE error of 2^-30: use it for activations, not for back-propagated gradients.  The vocoder handle
+ *      selects it by default (DMEL_PRECISION_FP32 there means "fp32-grade, library's choice"); WaveNet handles keep the six-product
+ *      split unless asked, because the encoder's token ids are defined by it; training entry points always use the six-product split.
+ *  FP32_BF16X3: force the six-product bf16 split where FP32 would pick the fp16 one.
  *  BF16: opt-in throughput mode, the library-side equivalent of running the reference's codec under dtype: bfloat16
  *      (config/lm/lm_config.yaml:1,83; models/lm_lit_modules.py:52-55): weights and staged activations rounded to bf16
  *      (nearest-even), fp32 accumulation; activations, biases, residuals and the quantizer stay fp32.  More accurate than
@@ -45,6 +55,8 @@ extern "C" {
 #define DMEL_PRECISION_FP32 0
 #define DMEL_PRECISION_BF16 1
 #define DMEL_PRECISION_FP32_MFMA 2
+#define DMEL_PRECISION_FP32_F16X2 3
+#define DMEL_PRECISION_FP32_BF16X3 4
 
 const char* dmel_last_error(void);
 /* ABI version of this header; bumped on any signature change. */
@@ -345,6 +357,11 @@ int dmel_conv_backward_weight(const dmel_conv* c, const float* x, const float* d
 int dmel_prof_enable(int on);
 int dmel_prof_reset(void);
 int dmel_prof_read(const char* family, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes);
+/* the same plus the matrix-core flops the launches ISSUED for those algorithmic flops (6x under the bf16 split, 3x under the fp16 split,
+ * 1x with bf16 operands; 0 for families without a matrix-core kernel): total_flops / (total_issue_flops / dense peak) is the family's
+ * matrix-core ceiling */
+int dmel_prof_read_ex(const char* family, int64_t* launches, double* total_ms, double* total_flops, double* total_bytes,
+                      double* total_issue_flops);
 
 #ifdef __cplusplus
 }

@@ -650,14 +650,58 @@ def test_split_fp32_conv_is_fp32_grade(dev, Cout, Cin, k, dil, T, B):
     try:
         xd = x.to(dev)
         errs = {}
-        for name, mode in (("split", 0), ("native", 2)):
+        for name, mode in (("split", 0), ("native", 2), ("f16x2", 3), ("bf16x3", 4)):
             _lib.check(L.dmel_conv_set_precision(h, mode))
             y = torch.empty(B, Cout, T, device=dev)
             _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
             torch.cuda.synchronize()
             errs[name] = rel_err(y, ref)
-        assert errs["native"] < 2e-6 and errs["split"] < 2e-6, errs
+            if name == "bf16x3":
+                assert errs[name] == errs["split"]
+        assert errs["native"] < 2e-6 and errs["split"] < 2e-6 and errs["f16x2"] < 2e-6, errs
         assert errs["split"] < 1.5 * errs["native"] + 1e-7, errs
+        assert errs["f16x2"] < 1.5 * errs["native"] + 1e-7, errs     # three fp16 products: the same fp32-grade result
+        from conftest import report
+        report(f"conv {Cout}x{Cin} k{k} d{dil} T{T}: error vs fp64  fp32-MFMA {errs['native']:.2e}  bf16x3 (6 products) {errs['split']:.2e}  "
+               f"f16x2 (3 products) {errs['f16x2']:.2e}")
+    finally:
+        L.dmel_conv_destroy(h)
+
+
+@pytest.mark.parametrize("scale", [1e-7, 1e-5, 1e-3, 1.0, 3e3, 5e5])
+def test_f16_split_conv_over_the_magnitude_range(dev, scale):
+    """DMEL_PRECISION_FP32_F16X2 (include/dmel_hip.h): the second fp16 piece is kept scaled by 2^11 and inputs are staged x 2^-6, so the
+    relative error stays at fp32 level from |x| ~ 1e-3 up to 4e6 and becomes an ABSOLUTE 2^-30 below |x| = 2^-8 (fp16 subnormals of the
+    first piece; the matrix core must not flush them)."""
+    from dmel_codec_amd import _lib
+    Cout, Cin, k, dil, T, B = 128, 96, 7, 3, 500, 2
+    torch.manual_seed(int(abs(math.log10(scale)) * 10) + 3)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    x = torch.randn(B, Cin, T) * scale
+    ref = F.conv1d(x.double(), w.double(), None, dilation=dil, padding=dil * (k - 1) // 2)
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), None, Cout, Cin, k, dil))
+    try:
+        xd = x.to(dev)
+        _lib.check(L.dmel_conv_set_precision(h, 3))
+        y = torch.empty(B, Cout, T, device=dev)
+        _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        err_abs = (y.double().cpu() - ref).abs().max().item()
+        # fp32-level relative error, or the absolute floor: K = 672 terms of <= 2^-30 |w| each, |w| ~ 0.04 (measured 2.5e-9 at |x| ~ 1e-7)
+        assert err_abs < max(2e-6 * ref.abs().max().item(), 2.0 ** -30 * 4.0), (scale, err_abs, ref.abs().max().item())
+        from conftest import report
+        report(f"f16x2 conv, |x| ~ {scale:g}: max abs error {err_abs:.3e} (max |y| {ref.abs().max().item():.3e})")
+        if scale == 5e5:      # beyond 2^6 * 65504 = 4.19e6 the first piece overflows: the result is non-finite, never a silently wrong number
+            xd[0, 3, 100] = 1e7
+            _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert not torch.isfinite(y[0, :, 100 - 9:100 + 10]).all()
+            _lib.check(L.dmel_conv_set_precision(h, 0))          # the six-product split has the range of fp32
+            _lib.check(L.dmel_conv_forward(h, xd.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.isfinite(y).all()
     finally:
         L.dmel_conv_destroy(h)
 
