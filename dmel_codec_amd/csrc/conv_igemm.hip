@@ -561,6 +561,15 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef DMEL_PD
 #define DMEL_PD 2   // weight prefetch distance in K steps
 #endif
+#ifndef DMEL_EXP
+#define DMEL_EXP 0   // what-if switches for profiling builds (wrong results): 2 no x staging, 4 no weight loads, 8 no epilogue
+#endif
+#ifndef DMEL_PD2
+#define DMEL_PD2 2  // ... of the fp16-split kernel (half the MFMA time per step)
+#endif
+#ifndef DMEL_KG2
+#define DMEL_KG2 2  // 8-channel groups staged per barrier by the fp16-split kernel when the convolution has taps
+#endif
 
 __device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {      // {bf16 bits of lo, bf16 bits of hi} by truncation
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
@@ -573,7 +582,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NTHR = 64 * WAVES_M * WAVES_N;
   constexpr int XS = BN + HALO;
   constexpr int SUB = KG / 2;                            // 16-channel K steps (per tap) per staged chunk
-  constexpr int NIT = (KG * XS + NTHR - 1) / NTHR;       // (group, column) items per thread per chunk
+  // Staging map: an item is (8-channel group kg, column j) -- eight channels of one staged column, i.e. one lane's B operand.  The group is
+  // WAVE-UNIFORM (a wave owns one group, or a segment of one, or a few whole groups), so the eight row addresses are scalar registers and
+  // a load is global_load_dword v, v_column_offset, s[row_base]: no vector address arithmetic per element.
+  constexpr int NWV = WAVES_M * WAVES_N;
+  static_assert(NWV % KG == 0 || KG % NWV == 0, "waves and staged channel groups must divide one another");
+  constexpr int SEG = NWV >= KG ? NWV / KG : 1;          // waves sharing one group's row of columns
+  constexpr int RPW = NWV >= KG ? 1 : KG / NWV;          // groups per wave
+  constexpr int SL = (XS + SEG - 1) / SEG;               // columns per wave and group
+  constexpr int NPASS = (SL + 63) / 64;
+  constexpr int NIT = RPW * NPASS;                       // items per thread per chunk
   constexpr int PSZ = KG * XS;                           // uint4 per piece
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint4* Xb = reinterpret_cast<uint4*>(smem);            // [2][NP][KG][XS] x 16 bytes
@@ -637,6 +655,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   // a K step of MFMAs later, so no s_waitcnt lands between the loads and the math.  Addresses are a scalar base (batch
   // item) plus one unsigned 32-bit byte offset per lane: row offsets advance by additions, clamped to the last channel.
   bool xok[NIT];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int st_kg0 = (wave_u / SEG) * RPW, st_j0 = (wave_u % SEG) * SL;
   auto load_x = [&](int sg, int chunk) {
     const char* xb = reinterpret_cast<const char*>(a.seg[sg].x + (int64_t)b * a.seg[sg].bstride);
     const int taps = a.seg[sg].taps, dil = a.seg[sg].dil, tstride = a.seg[sg].tstride, Cin = a.seg[sg].Cin;
@@ -646,28 +666,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     const int tau0 = q0 * tstride + a.seg[sg].toff - a.seg[sg].pad_left;
     const uint32_t cs4 = (uint32_t)a.seg[sg].cstride * 4u, last = (uint32_t)(Cin - 1) * cs4;
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int i = min(tid + it * NTHR, KG * XS - 1);
-      const int kg = i / XS, j = i - kg * XS;
-      const int tau = tau0 + j * tstride;
-      xok[it] = (j < wx) && (tau >= 0) && (tau < lim);
-      const uint32_t col = (uint32_t)min(max(tau, 0), tin - 1) * 4u;
-      uint32_t row = (uint32_t)(chunk * (KG * 8) + kg * 8) * cs4;
+    for (int rr = 0; rr < RPW; ++rr) {
+      // rows past the last channel are clamped, not zeroed: their weights are zero in the packed image (conv.h pack_conv)
+      uint32_t row = (uint32_t)(chunk * (KG * 8) + (st_kg0 + rr) * 8) * cs4;      // scalar
+      const char* rowp[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e, row += cs4) xr[it][e] = *reinterpret_cast<const float*>(xb + (min(row, last) + col));
+      for (int e = 0; e < 8; ++e, row += cs4) rowp[e] = xb + min(row, last);
+#pragma unroll
+      for (int ps = 0; ps < NPASS; ++ps) {
+        const int it = rr * NPASS + ps;
+        const int j = min(st_j0 + ps * 64 + lane, XS - 1);
+        const int tau = tau0 + j * tstride;
+        xok[it] = (j < wx) && (tau >= 0) && (tau < lim);
+        const uint32_t col = (uint32_t)min(max(tau, 0), tin - 1) * 4u;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xr[it][e] = *reinterpret_cast<const float*>(rowp[e] + col);
+      }
     }
   };
   auto store_x = [&](uint4* dst, int sg, int chunk) {
     const float scale = NP == 2 ? a.seg[sg].in_scale * kF16XScale : a.seg[sg].in_scale;
-    const int Cin = a.seg[sg].Cin;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int i = tid + it * NTHR;
-      if ((KG * XS) % NTHR != 0 && i >= KG * XS) continue;
-      const int c0 = chunk * (KG * 8) + (i / XS) * 8;
+      const int rr = it / NPASS, ps = it % NPASS;
+      const int jl = ps * 64 + lane;                         // column inside this wave's segment
+      const int j = st_j0 + jl;
+      if ((SL % 64 != 0 && jl >= SL) || (XS % SL != 0 && j >= XS)) continue;
+      const int i = (st_kg0 + rr) * XS + j;
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (xok[it] && c0 + e < Cin) ? xr[it][e] * scale : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (xok[it] ? xr[it][e] : 0.f) * scale;
       if constexpr (NP == 1) {
         bf16x8 p;
 #pragma unroll
@@ -676,10 +704,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
       } else if constexpr (NP == 2) {
         f16x8 ph, pl;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const _Float16 hi = (_Float16)v[e];                       // v_cvt_f16_f32: round to nearest even, subnormals kept
-          ph[e] = hi;
-          pl[e] = (_Float16)((v[e] - (float)hi) * kF16LoScale);     // the subtraction is exact
+        for (int e = 0; e < 8; e += 2) {
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          // v_cvt_pk_f16_f32: round to nearest even, subnormals kept; the subtraction below is exact
+          const f16x2 hi = __builtin_convertvector((f32x2){v[e], v[e + 1]}, f16x2);
+          const f16x2 lo = __builtin_convertvector((f32x2){(v[e] - (float)hi[0]) * kF16LoScale, (v[e + 1] - (float)hi[1]) * kF16LoScale}, f16x2);
+          ph[e] = hi[0]; ph[e + 1] = hi[1];
+          pl[e] = lo[0]; pl[e + 1] = lo[1];
         }
         dst[i] = __builtin_bit_cast(uint4, ph);
         dst[PSZ + i] = __builtin_bit_cast(uint4, pl);
@@ -719,7 +750,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   // Weight loads first, x loads last in the prologue: store_x then waits for the youngest load, so nothing is outstanding
   // when the loop is entered (a prologue load still pending at loop entry forces a static s_waitcnt vmcnt(0) into the loop
   // body, which then drains the NEXT steps' weight prefetch in every iteration).
-  constexpr int PD = DMEL_PD;
+  constexpr int PD = NP == 2 ? DMEL_PD2 : DMEL_PD;
   uint4 wa[PD + 1][MT][NP];
 #pragma unroll
   for (int d = 0; d < PD; ++d) load_w(wa[d], min(d, a.steps - 1));
@@ -757,7 +788,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     const bool has_next = s + 1 < a.steps;
     // unconditional (the last PD steps re-fetch the final step's fragments into a set nobody reads again): a branch here
     // would put a wait-free path into the CFG and with it a conservative vmcnt(0) in front of the MFMAs
-    load_w(wa[(r + PD) % (PD + 1)], min(s + PD, a.steps - 1));
+    if (!(DMEL_EXP & 4)) load_w(wa[(r + PD) % (PD + 1)], min(s + PD, a.steps - 1));
     {
       const uint4* xp = Xb + xbuf * (NP * PSZ) + ((c16 % SUB) * 2 + h) * XS + wave_n * (NT * 32) + l31 + tap * cur_dil;
       bf16x8 bcur[NT][NP];
@@ -791,9 +822,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     __builtin_amdgcn_s_waitcnt(kWaitW);
     if (cstep == 0) {
       pending = next_chunk(sg, c16 / SUB, psg, pck);
-      if (pending) load_x(psg, pck);
+      if (pending && !(DMEL_EXP & 2)) load_x(psg, pck);
+      if (DMEL_EXP & 2) pending = false;
     }
-    if (pending && (cstep == 1 || newx)) {       // second step of the chunk, or its only one
+    if (pending && (((DMEL_EXP & 1) ? false : cstep == 1) || newx)) {       // second step of the chunk, or its only one
       store_x(Xb + (xbuf ^ 1) * (NP * PSZ), psg, pck);
       pending = false;
     }
@@ -825,6 +857,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaf(acl[mi][ni][r], 1.f / kF16LoScale, acc[mi][ni][r]);
   }
+  if ((DMEL_EXP & 8) && acc[0][0][0] != 12345.f) return;
   conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
 }
 
@@ -848,8 +881,9 @@ template <int WM, int WN, int MT, int NT, int MODE, int NP> static int launch_b1
   constexpr int KG0 = (WN * NT * 32 >= 256 && NP == 3) ? 2 : 4;       // keep the widest tile inside 64 KiB of LDS
   if (halo == 0) return launch_b16k<WM, WN, MT, NT, MODE, 0, NP, KG0>(ka, B, mblocks, st);
   // dilation-1 convs (every second conv of an AMP block, k2 transposed-conv phases): a 16-column halo is enough
-  if (halo <= 16) return launch_b16k<WM, WN, MT, NT, MODE, 16, NP, 2>(ka, B, mblocks, st);
-  return launch_b16k<WM, WN, MT, NT, MODE, 64, NP, 2>(ka, B, mblocks, st);
+  constexpr int KGT = (NP == 2 && 2 * NP * DMEL_KG2 * (WN * NT * 32 + 64) * 16 <= 65536) ? DMEL_KG2 : 2;
+  if (halo <= 16) return launch_b16k<WM, WN, MT, NT, MODE, 16, NP, KGT>(ka, B, mblocks, st);
+  return launch_b16k<WM, WN, MT, NT, MODE, 64, NP, KGT>(ka, B, mblocks, st);
 }
 
 template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int tile, int B, hipStream_t st) {
