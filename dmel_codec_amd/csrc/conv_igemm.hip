@@ -667,7 +667,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     const uint32_t cs4 = (uint32_t)a.seg[sg].cstride * 4u, last = (uint32_t)(Cin - 1) * cs4;
 #pragma unroll
     for (int rr = 0; rr < RPW; ++rr) {
-      // rows past the last channel are clamped, not zeroed: their weights are zero in the packed image (conv.h pack_conv)
+      // rows past the last channel are clamped here and multiplied by a scalar zero in store_x
       uint32_t row = (uint32_t)(chunk * (KG * 8) + (st_kg0 + rr) * 8) * cs4;      // scalar
       const char* rowp[8];
 #pragma unroll
@@ -685,7 +685,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     }
   };
   auto store_x = [&](uint4* dst, int sg, int chunk) {
+    // No contraction in here: the scaled input is ROUNDED to fp32 and then split.  Fused into the first subtraction of the split (fma), the
+    // pieces would sum to the unrounded product, and the whole-stack WaveNet kernel, which rounds, would differ in the last bit.
+#pragma clang fp contract(off)
     const float scale = NP == 2 ? a.seg[sg].in_scale * kF16XScale : a.seg[sg].in_scale;
+    const int Cin = a.seg[sg].Cin;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int rr = it / NPASS, ps = it % NPASS;
@@ -693,9 +697,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
       const int j = st_j0 + jl;
       if ((SL % 64 != 0 && jl >= SL) || (XS % SL != 0 && j >= XS)) continue;
       const int i = (st_kg0 + rr) * XS + j;
+      const int c0 = chunk * (KG * 8) + (st_kg0 + rr) * 8;        // scalar: the group's first channel
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (xok[it] ? xr[it][e] : 0.f) * scale;
+      for (int e = 0; e < 8; ++e) v[e] = (xok[it] ? xr[it][e] : 0.f) * (c0 + e < Cin ? scale : 0.f);
       if constexpr (NP == 1) {
         bf16x8 p;
 #pragma unroll
@@ -887,9 +892,9 @@ template <int WM, int WN, int MT, int NT, int MODE, int NP> static int launch_b1
 }
 
 template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int tile, int B, hipStream_t st) {
-  const int bm[6] = {128, 128, 64, 32, 128, 64};
+  const int bm[8] = {128, 128, 64, 32, 128, 64, 128, 256};
   // bf16 tiles: 0: 128x128 (2,2,2,2), 1: 128x96 (4,1,1,3), 2: 64x128 (2,2,1,2), 3: 32x256 (1,4,1,2), 4: 128x128 (4,1,1,4),
-  // 5: 64x128 (2,1,1,4)
+  // 5: 64x128 (2,1,1,4), 6: 128x64 (4,1,1,2), 7: 256x96 (8,1,1,3: eight waves)
   const int mblocks = (ka.mtiles * 32 + bm[tile] - 1) / bm[tile];
   switch (tile) {
     case 0: return launch_b16<2, 2, 2, 2, MODE, NP>(ka, B, mblocks, st);
@@ -897,6 +902,8 @@ template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int til
     case 2: return launch_b16<2, 2, 1, 2, MODE, NP>(ka, B, mblocks, st);
     case 3: return launch_b16<1, 4, 1, 2, MODE, NP>(ka, B, mblocks, st);
     case 4: return launch_b16<4, 1, 1, 4, MODE, NP>(ka, B, mblocks, st);
+    case 6: return launch_b16<4, 1, 1, 2, MODE, NP>(ka, B, mblocks, st);
+    case 7: return launch_b16<8, 1, 1, 3, MODE, NP>(ka, B, mblocks, st);
     default: return launch_b16<2, 1, 1, 4, MODE, NP>(ka, B, mblocks, st);
   }
 }
@@ -906,17 +913,21 @@ template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int til
 // T = 92 / 736); 64-row problems on 64x128, 32-row problems on 32x256.
 // NP = 2 (two accumulator sets): the 96-column tile keeps 2-3 waves per SIMD where the 128-column one has 208 registers, and wins at every
 // length (bv2, 128 rows x 5888 columns: 176 / 233 / 250 TF/s against 117 / 182 / 206).
-static int pick_tile_bf16(int mtiles, int64_t T, int np) {
+// Within NP = 2 (MI355X, tools/bench_conv.py --precision 3): 256-row problems with long rows gain 5-8 % from the eight-wave 256 x 96 tile (x is
+// converted once per 256 rows); 128-row problems with >= 40 K steps gain 6-17 % from 128 x 64 (124 registers, four waves per SIMD).
+static int pick_tile_bf16(int mtiles, int64_t T, int np, int steps) {
   const char* e = getenv("DMEL_CONV_TILE_BF16");        // per call: tools/ab_wavenet.py switches tiles inside one process
   const int forced = e ? atoi(e) : -1;
-  if (forced >= 0 && forced < 6) return forced;
+  if (forced >= 0 && forced < 8) return forced;
+  if (np == 2 && mtiles >= 8 && T > 96) return 7;
+  if (np == 2 && mtiles >= 4 && mtiles < 8 && steps >= 40) return 6;
   if (mtiles >= 4) return (T > 2048 && np != 2) ? 4 : 1;
   if (mtiles >= 2) return 2;
   return 3;
 }
 
 template <int NP> static int launch_bf16_any(const KArgs& ka, EpiMode mode, int B, int64_t Tcols, hipStream_t st) {
-  const int t16 = pick_tile_bf16(ka.mtiles, Tcols, NP);
+  const int t16 = pick_tile_bf16(ka.mtiles, Tcols, NP, ka.steps);
   switch (mode) {
     case EPI_LINEAR: return launch_mode_bf16<EPI_LINEAR, NP>(ka, t16, B, st);
     case EPI_GATE: return launch_mode_bf16<EPI_GATE, NP>(ka, t16, B, st);

@@ -1806,6 +1806,8 @@ int disc_layer_forward(const dmel_discriminator* d, const DPlan& p, int i, int B
     }
     r.B = B; r.Tcols = Tout; r.y = out; r.y_bs = l.Cout * Tout; r.y_cs = Tout; r.Tout = Tout;
     r.accumulate = k > 0;
+    // forward activations (log-mel images, SiLU outputs) sit in the fp16 split's range; the backward pass keeps the six-product split
+    r.precision = DMEL_PRECISION_FP32_F16X2;
     DMEL_TRY(launch_conv(l.fwd[dh], r, st));
   }
   return DMEL_OK;
