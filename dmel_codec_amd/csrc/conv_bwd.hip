@@ -35,6 +35,11 @@ struct WgArgs {
   // short rows (T <= 32: the deep discriminator layers have 12-24 frames per image row): ipc = 64 / T batch items share one staged
   // 64-sample step, lane -> (item lane / T, sample lane % T); 1 = one item per step
   int ipc;
+  // fp16-split instantiation: bit pattern of max |dy| of the launch (device memory, written by absmax_kernel on the same stream)
+  const uint32_t* dy_absmax;
+  // three-tap kernel: raw accumulator tiles of every workgroup ([workgroup][tap][wave][16][64] floats), summed over the K slices by
+  // wgrad_reduce_kernel -- no atomics (thousands of device-scope float atomics on a few 10^5 addresses cost more than the GEMM)
+  float* partial;
 };
 
 // grid (ceil(Cin/64), ceil(Cout/64), taps * slices); 256 threads = 2 x 2 waves of 32 x 32
@@ -131,13 +136,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 // 16-byte units -- exactly one lane's MFMA operand -- into the piece planes of the LDS tile.
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef __bf16 wg_bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kSpRow = 9;         // uint4 units per LDS row: 64 bf16 + 8 pad -> rows 36 banks apart, 128-bit reads conflict-free
 
 __device__ __forceinline__ uint32_t wg_pack_hi16(float lo, float hi) {
   return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
 }
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
+typedef float wg_f32x2 __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ __forceinline__ void wg_split_store(const float (&v)[8], uint4* plane0, int plane_stride, int idx) {
+  if constexpr (NP == 2) {          // two fp16 pieces, the second one scaled by 2^11 (conv_igemm.hip, "fp16 split"); v is already scaled
+    wg_f16x8 ph, pl;
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      const wg_f16x2 hi = __builtin_convertvector((wg_f32x2){v[e], v[e + 1]}, wg_f16x2);
+      const wg_f16x2 lo = __builtin_convertvector((wg_f32x2){(v[e] - (float)hi[0]) * kF16LoScale, (v[e + 1] - (float)hi[1]) * kF16LoScale}, wg_f16x2);
+      ph[e] = hi[0]; ph[e + 1] = hi[1];
+      pl[e] = lo[0]; pl[e + 1] = lo[1];
+    }
+    plane0[idx] = __builtin_bit_cast(uint4, ph);
+    plane0[plane_stride + idx] = __builtin_bit_cast(uint4, pl);
+    return;
+  }
   if constexpr (NP == 1) {
     wg_bf16x8 p;
 #pragma unroll
@@ -182,12 +202,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
   const int tap = blockIdx.z % a.taps, slice = blockIdx.z / a.taps;
   const int shift = tap * a.dil - a.pad;
   floatx16 acc[MT][NT];
+  floatx16 acl[NP == 2 ? MT : 1][NP == 2 ? NT : 1];            // NP = 2: the cross terms, 2^11 times their size
 #pragma unroll
   for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+      for (int r = 0; r < 16; ++r) {
+        acc[mi][ni][r] = 0.f;
+        if constexpr (NP == 2) acl[mi][ni][r] = 0.f;
+      }
+  // NP = 2: gradients span too many binades for fp16 as they are: dy is staged x 2^(13 - e), e the exponent of the launch's max |dy|
+  // (absmax_kernel), so that the largest gradient lands in [2^13, 2^14) and everything within 2^-28 of it keeps 2^-24 relative precision;
+  // x is staged x 2^-6 like the forward kernel.  The product of the two scales is undone on the accumulators.
+  float dy_mul = 1.f, x_mul = 1.f, out_mul = 1.f;
+  if constexpr (NP == 2) {
+    const uint32_t mb = *a.dy_absmax;
+    const int e = min(max((int)(mb >> 23) - 127, -100), 100);
+    dy_mul = __uint_as_float((uint32_t)(127 + 13 - e) << 23);
+    x_mul = kF16XScale;
+    out_mul = __uint_as_float((uint32_t)(127 - 13 + e) << 23) * (1.f / kF16XScale);
+  }
   const int total = a.B * a.chunks_per_item;
   const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
   const int r31 = lane & 31, hh = lane >> 5;
@@ -271,14 +306,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
     for (int ps = 0; ps < PD; ++ps) {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (md[S][ps] >> e) & 1 ? rd[S][ps][e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (md[S][ps] >> e) & 1 ? (NP == 2 ? rd[S][ps][e] * dy_mul : rd[S][ps][e]) : 0.f;
       wg_split_store<NP>(v, dys, kPlaneD, (srow + RP * ps) * UR + sg);
     }
 #pragma unroll
     for (int ps = 0; ps < PX; ++ps) {
       float v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (mx[S][ps] >> e) & 1 ? rx[S][ps][e] : 0.f;
+      for (int e = 0; e < 8; ++e) v[e] = (mx[S][ps] >> e) & 1 ? (NP == 2 ? rx[S][ps][e] * x_mul : rx[S][ps][e]) : 0.f;
       wg_split_store<NP>(v, xs, kPlaneX, (srow + RP * ps) * UR + sg);
     }
     __syncthreads();
@@ -295,14 +330,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) bf[ni][pc] = __builtin_bit_cast(wg_bf16x8, bp[pc * kPlaneX + ni * 32 * UR + 2 * kk]);
       }
-      constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
-#pragma unroll
-      for (int u = 0; u < (NP == 3 ? 6 : 1); ++u)
+      if constexpr (NP == 2) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NT; ++ni)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][NP == 3 ? PA[u] : 0], bf[ni][NP == 3 ? PB[u] : 0], acc[mi][ni], 0, 0, 0);
+          for (int ni = 0; ni < NT; ++ni) {
+            const wg_f16x8 ah = __builtin_bit_cast(wg_f16x8, af[mi][0]), al = __builtin_bit_cast(wg_f16x8, af[mi][1]);
+            const wg_f16x8 bh = __builtin_bit_cast(wg_f16x8, bf[ni][0]), bl = __builtin_bit_cast(wg_f16x8, bf[ni][1]);
+            acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acl[mi][ni], 0, 0, 0);
+            acl[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acl[mi][ni], 0, 0, 0);
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[mi][ni], 0, 0, 0);
+          }
+      } else {
+        constexpr int PA[6] = {2, 1, 0, 1, 0, 0}, PB[6] = {0, 1, 2, 0, 1, 0};   // smallest partial products first
+#pragma unroll
+        for (int u = 0; u < (NP == 3 ? 6 : 1); ++u)
+#pragma unroll
+          for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi][NP == 3 ? PA[u] : 0], bf[ni][NP == 3 ? PB[u] : 0], acc[mi][ni], 0, 0, 0);
+      }
     }
   };
   using S0 = std::integral_constant<int, 0>;
@@ -325,10 +373,195 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int co = co0 + (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps_out + a.tap_out + tap, acc[mi][ni][r]);
+          float v = acc[mi][ni][r];
+          if constexpr (NP == 2) v = fmaf(acl[mi][ni][r], 1.f / kF16LoScale, v) * out_mul;
+          if (co < a.Cout) atomicAdd(a.dw + ((int64_t)co * a.Cin + ci) * a.taps_out + a.tap_out + tap, v);
         }
       }
     }
+}
+
+// ---- three taps per workgroup (fp16 split) -------------------------------------------------------------------------------------
+// The kernels above give every (tap, tile, K slice) its own workgroup, so a 64 x 64 dy tile is fetched from L2 and converted once per TAP
+// and a step moves 32 KB for 0.5 MFLOP: the discriminator's 27-tap layers are bound by that traffic, not by the matrix core.  Here a workgroup
+// owns THREE adjacent taps of a unit-dilation convolution: the dy tile is staged once, the x window (8 XS + 2 samples per thread instead of
+// 3 x 8) once, the three shifted x tiles are cut from it in registers -- 2.8x fewer bytes and 1.5x fewer conversions per flop.  Operands are the
+// fp16 split of conv_igemm.hip (two pieces, three products, two accumulator sets per tap); dy is scaled by the launch's max (absmax_kernel).
+// grid (ceil(Cin / 64), ceil(Cout / 64), taps / 3 * slices); 73.7 KB of dynamic LDS: [dy | x tap 0 | x tap 1 | x tap 2] x [hi, lo] planes.
+typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
+template <int XS>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_f16g_kernel(WgArgs a) {
+  constexpr int TG = 3, KS = 64, UR = KS / 8 + 1, G = KS / 8, RP = 256 / G, PS = 64 / RP;
+  constexpr int W = 8 * XS + (TG - 1);                           // x samples a thread needs for its 8 output samples and 3 taps
+  constexpr int kPlane = 64 * UR;
+  extern __shared__ uint4 wg_lds[];
+  uint4* const dys = wg_lds;
+  uint4* const xs = wg_lds + 2 * kPlane;                         // tap g at xs + g * 2 * kPlane
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64;
+  const int groups = a.taps / TG;
+  const int tap0 = (blockIdx.z % groups) * TG, slice = blockIdx.z / groups;
+  const int shift = tap0 - a.pad;                                 // dilation 1
+  floatx16 acc[TG], acl[TG];
+#pragma unroll
+  for (int g = 0; g < TG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[g][r] = 0.f; acl[g][r] = 0.f; }
+  const uint32_t mb = *a.dy_absmax;
+  const int ex = min(max((int)(mb >> 23) - 127, -100), 100);
+  const float dy_mul = __uint_as_float((uint32_t)(127 + 13 - ex) << 23), x_mul = kF16XScale;
+  const float out_mul = __uint_as_float((uint32_t)(127 - 13 + ex) << 23) * (1.f / kF16XScale);
+  const int total = a.B * a.chunks_per_item;
+  const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
+  // (an empty K slice still writes its zero tiles: the reduction reads every slice)
+  const int r31 = lane & 31, hh = lane >> 5;
+  const int srow = tid / G, sg = tid % G;
+
+  // one register set: a step's values are consumed by the staging at its top and the next step's loads are issued right behind it, so they
+  // have the 36 MFMAs of the step to arrive
+  float rd[PS][8], rx[PS][W];
+  unsigned md[PS], mx[PS];
+  auto fetch = [&](int c) {
+    const int b = c / a.chunks_per_item;
+    const int t0 = (c - b * a.chunks_per_item) * KS;
+    const int t = t0 + 8 * sg;
+    const int txs = t * XS + a.xoff + shift;
+    const float* dyb = a.dy + (int64_t)b * a.Cout * a.T;
+    const float* xb = a.x + (int64_t)b * a.Cin * a.Tx;
+    const int xw0 = t0 * XS + a.xoff + shift;
+    const bool interior = t0 + KS <= a.T && xw0 >= 0 && xw0 + KS * XS + TG - 1 <= a.Tx;       // wave-uniform; covers the W floats every thread loads
+    if (interior) {
+#pragma unroll
+      for (int ps = 0; ps < PS; ++ps) {
+        const int co = co0 + srow + RP * ps, ci = ci0 + srow + RP * ps;
+        const float* p = dyb + (int64_t)min(co, a.Cout - 1) * a.T + t;
+        const float* q = xb + (int64_t)min(ci, a.Cin - 1) * a.Tx + txs;
+        const f4u u0 = *reinterpret_cast<const f4u*>(p), u1 = *reinterpret_cast<const f4u*>(p + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { rd[ps][e] = u0[e]; rd[ps][4 + e] = u1[e]; }
+        md[ps] = co < a.Cout ? 0xffu : 0u;
+#pragma unroll
+        for (int e4 = 0; e4 < (W - 2) / 4; ++e4) {
+          const f4u w4 = *reinterpret_cast<const f4u*>(q + 4 * e4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rx[ps][4 * e4 + e] = w4[e];
+        }
+        const f2u w2 = *reinterpret_cast<const f2u*>(q + W - 2);
+        rx[ps][W - 2] = w2[0]; rx[ps][W - 1] = w2[1];
+        mx[ps] = ci < a.Cin ? (1u << W) - 1u : 0u;
+      }
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < PS; ++ps) {
+        const int co = co0 + srow + RP * ps, ci = ci0 + srow + RP * ps;
+        const float* p = dyb + (int64_t)min(co, a.Cout - 1) * a.T;
+        const float* q = xb + (int64_t)min(ci, a.Cin - 1) * a.Tx;
+        unsigned m = 0;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          rd[ps][e] = p[min(t + e, a.T - 1)];
+          m |= (unsigned)(t + e < a.T) << e;
+        }
+        md[ps] = co < a.Cout ? m : 0u;
+        m = 0;
+#pragma unroll
+        for (int e = 0; e < W; ++e) {
+          const int tx = txs + e;
+          rx[ps][e] = q[min(max(tx, 0), a.Tx - 1)];
+          m |= (unsigned)(tx >= 0 && tx < a.Tx) << e;
+        }
+        mx[ps] = ci < a.Cin ? m : 0u;
+      }
+    }
+  };
+  if (c_begin < c_end) fetch(c_begin);
+  for (int c = c_begin; c < c_end; ++c) {
+    __syncthreads();      // the previous step's fragment reads are done
+#pragma unroll
+    for (int ps = 0; ps < PS; ++ps) {
+      const int idx = (srow + RP * ps) * UR + sg;
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (md[ps] >> e) & 1 ? rd[ps][e] * dy_mul : 0.f;
+      wg_split_store<2>(v, dys, kPlane, idx);
+      // an output sample past the end of dy's row has a zero dy factor, so x needs no extra mask for it
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (mx[ps] >> (e * XS + g)) & 1 ? rx[ps][e * XS + g] * x_mul : 0.f;
+        wg_split_store<2>(v, xs + g * 2 * kPlane, kPlane, idx);
+      }
+    }
+    __syncthreads();
+    fetch(min(c + 1, c_end - 1));      // unconditional (the last step re-reads itself): the load count per step stays static
+    const uint4* ap = dys + (wm * 32 + r31) * UR + hh;
+    const uint4* bp = xs + (wn * 32 + r31) * UR + hh;
+#pragma unroll
+    for (int kk = 0; kk < KS / 16; ++kk) {
+      const wg_f16x8 ah = __builtin_bit_cast(wg_f16x8, ap[2 * kk]), al = __builtin_bit_cast(wg_f16x8, ap[kPlane + 2 * kk]);
+#pragma unroll
+      for (int g = 0; g < TG; ++g) {
+        const wg_f16x8 bh = __builtin_bit_cast(wg_f16x8, bp[g * 2 * kPlane + 2 * kk]);
+        const wg_f16x8 bl = __builtin_bit_cast(wg_f16x8, bp[g * 2 * kPlane + kPlane + 2 * kk]);
+        acl[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acl[g], 0, 0, 0);
+        acl[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acl[g], 0, 0, 0);
+        acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[g], 0, 0, 0);
+      }
+    }
+  }
+  const int64_t wg = ((int64_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  float* dst = a.partial + ((wg * TG) * 4 + wave) * 1024 + lane;
+#pragma unroll
+  for (int g = 0; g < TG; ++g)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[(int64_t)g * 4096 + r * 64] = fmaf(acl[g][r], 1.f / kF16LoScale, acc[g][r]) * out_mul;
+}
+constexpr size_t kWgF16gLds = (size_t)4 * 2 * 64 * (64 / 8 + 1) * 16;
+
+// dw[co, ci, tap_out + tap] += sum over the K slices of the three-tap kernel's partial tiles.  One thread per (co, ci, tap) of the launch.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw, int Cout, int Cin, int taps,
+                                                           int taps_out, int tap_out, int tm, int tn, int slices) {
+  const int64_t n = (int64_t)Cout * Cin * taps;
+  const int groups = taps / 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % Cin);
+    const int tap = (int)((i / Cin) % taps);
+    const int co = (int)(i / ((int64_t)Cin * taps));
+    const int y = co >> 6, x = ci >> 6, wave = ((co >> 5) & 1) * 2 + ((ci >> 5) & 1);
+    const int rr = co & 31, hh = (rr >> 2) & 1, r = (rr & 3) + 4 * (rr >> 3), lane = (ci & 31) + 32 * hh;
+    const int grp = tap / 3, g = tap - 3 * grp;
+    const int64_t tile_stride = (int64_t)groups * tm * tn * 3 * 4096;            // one K slice
+    const float* p = partial + ((((int64_t)grp * tm + y) * tn + x) * 3 + g) * 4096 + wave * 1024 + r * 64 + lane;
+    float sum = 0.f;
+    for (int sl = 0; sl < slices; ++sl) sum += p[sl * tile_stride];
+    dw[((int64_t)co * Cin + ci) * taps_out + tap_out + tap] += sum;
+  }
+}
+
+// max |v| over n floats as a bit pattern (non-negative floats order like unsigned integers); *out zeroed by the launcher
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ v, int64_t n, uint32_t* out) {
+  uint32_t m = 0;
+  const int64_t head = min(n, (int64_t)((4 - ((reinterpret_cast<uintptr_t>(v) >> 2) & 3)) & 3));      // floats up to 16-byte alignment
+  const int64_t n4 = (n - head) >> 2, tail0 = head + 4 * n4;
+  const uint4* v4 = reinterpret_cast<const uint4*>(v + head);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint4 q = v4[i];
+    m = max(max(m, q.x & 0x7fffffffu), max(max(q.y & 0x7fffffffu, q.z & 0x7fffffffu), q.w & 0x7fffffffu));
+  }
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < head) m = max(m, __float_as_uint(v[threadIdx.x]) & 0x7fffffffu);
+    if (threadIdx.x >= 64 && threadIdx.x - 64 < n - tail0) m = max(m, __float_as_uint(v[tail0 + threadIdx.x - 64]) & 0x7fffffffu);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+  __shared__ uint32_t part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {           // one atomic per workgroup: thousands of them on one word serialise for longer than the reduction takes
+    m = max(max(part[0], part[1]), max(part[2], part[3]));
+    if (m != 0) atomicMax(out, min(m, 0x7f7fffffu));      // inf / NaN gradients: scale as for the largest finite value
+  }
 }
 
 // DMEL_WGRAD_FP32_MFMA=1 keeps every weight gradient on the native fp32 MFMA kernel (A/B switch)
@@ -344,21 +577,83 @@ static bool wgrad_big_tile() {
   return v;
 }
 // picks the kernel, then the K slicing for its tile and step (a: everything but chunks_per_item / ipc / slices / chunks_per_slice)
-static void launch_wgrad_any(WgArgs a, hipStream_t st) {
+static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.ipc = a.T <= 32 ? kWgK / a.T : 1;
   // short rows are mostly boundary steps (scalar loads in the split kernel): they stay on the fp32-MFMA kernel
   const bool split = a.ipc == 1 && !wgrad_native_only() && a.xstride <= 2 && a.T >= 256;
+  a.dy_absmax = nullptr;
+  if (split && train_precision_override() != DMEL_PRECISION_BF16) {
+    // scale of the fp16 split: max |dy| of this launch, reduced on the same stream into one of a ring of device words (launches of one
+    // thread are ordered on their stream; the ring keeps earlier launches' words alive while later ones are queued)
+    static thread_local DevBuf ring;
+    static thread_local unsigned next = 0;
+    constexpr unsigned kSlots = 1024;
+    if (!ring.p) {
+      DMEL_HIP(hipMalloc(&ring.p, kSlots * sizeof(uint32_t)));
+      ring.bytes = kSlots * sizeof(uint32_t);
+    }
+    uint32_t* slot = ring.as<uint32_t>() + (next++ % kSlots);
+    DMEL_HIP(hipMemsetAsync(slot, 0, sizeof(uint32_t), st));
+    const int64_t n = (int64_t)a.B * a.Cout * a.T;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 512);
+    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, a.dy, n, slot);
+    DMEL_HIP(hipGetLastError());
+    a.dy_absmax = slot;
+  }
   // bf16 training mode (TrainPrecisionScope): long rows take the one-piece instantiation of the split kernel; short rows (the 92-frame
   // WaveNet GEMMs, packed image rows) stay on the exact fp32-MFMA kernel, which is at least as accurate
   const bool bf16 = split && train_precision_override() == DMEL_PRECISION_BF16;
-  const bool big = split && !bf16 && a.Cout >= 128 && a.Cin >= 128 && wgrad_big_tile();
+  // fp32 mode: long rows take the fp16-split instantiation (three products, cheaper operand conversion; DMEL_WGRAD_F16X2=0: the six-product one)
+  static const bool f16_off = [] { const char* e = getenv("DMEL_WGRAD_F16X2"); return e && e[0] == '0'; }();
+  const bool f16 = split && !bf16 && !f16_off && a.dy_absmax != nullptr;
+  static const bool group_off = [] { const char* e = getenv("DMEL_WGRAD_TAPGROUP"); return e && e[0] == '0'; }();
+  const bool grouped = f16 && !group_off && a.dil == 1 && a.taps % 3 == 0;
+  if (grouped) {
+    a.chunks_per_item = (a.T + 63) / 64;
+    const int tm = (a.Cout + 63) / 64, tn = (a.Cin + 63) / 64, groups = a.taps / 3;
+    const int total = a.B * a.chunks_per_item;
+    // ~1024 workgroups (two per CU resident): 256 -> 33.9 ms, 512 -> 30.4, 1024 -> 29.9, 2048 -> 29.8 ms of weight-gradient time per training step
+    const char* we = getenv("DMEL_WGRAD_WANT");
+    const int wantg = we ? atoi(we) : 1024;
+    int slices = std::max(1, std::min((wantg + tm * tn * groups - 1) / (tm * tn * groups), (total + 7) / 8));
+    slices = std::min(slices, 65535 / groups);
+    a.slices = slices;
+    a.chunks_per_slice = (total + slices - 1) / slices;
+    const dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)(groups * slices));
+    static const bool attr_ok = [] {
+      return hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16g_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgF16gLds) == hipSuccess &&
+             hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16g_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgF16gLds) == hipSuccess;
+    }();
+    if (!attr_ok) { set_error("conv_wgrad: could not raise the dynamic LDS limit to %zu bytes", kWgF16gLds); return DMEL_EUNSUPPORTED; }
+    // partial tiles of all workgroups: library-owned scratch, reused by every launch of this thread (launches and their reductions are
+    // ordered on the stream; a second stream driven by the same thread would need its own buffer)
+    static thread_local DevBuf scratch;
+    const size_t need = (size_t)tn * tm * groups * slices * 3 * 4096 * sizeof(float);
+    if (scratch.bytes < need) {
+      DMEL_HIP(hipStreamSynchronize(st));
+      scratch.release();
+      DMEL_HIP(hipMalloc(&scratch.p, need));
+      scratch.bytes = need;
+    }
+    a.partial = scratch.as<float>();
+    if (a.xstride == 1) hipLaunchKernelGGL(conv_wgrad_f16g_kernel<1>, grid, dim3(256), kWgF16gLds, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_f16g_kernel<2>, grid, dim3(256), kWgF16gLds, st, a);
+    DMEL_HIP(hipGetLastError());
+    const int64_t nout = (int64_t)a.Cout * a.Cin * a.taps;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)std::min<int64_t>((nout + 255) / 256, 4096)), dim3(256), 0, st, a.partial, a.dw, a.Cout,
+                       a.Cin, a.taps, a.taps_out, a.tap_out, tm, tn, slices);
+    DMEL_HIP(hipGetLastError());
+    return DMEL_OK;
+  }
+  const bool big = split && !bf16 && !f16 && a.Cout >= 128 && a.Cin >= 128 && wgrad_big_tile();
   const int tile = big ? 128 : kWgTile, ks = big ? 32 : kWgK;
   a.chunks_per_item = (a.T + ks - 1) / ks;
   const int tm = (a.Cout + tile - 1) / tile, tn = (a.Cin + tile - 1) / tile;
   const int tiles = tm * tn * a.taps;
   const int total = a.ipc > 1 ? (a.B + a.ipc - 1) / a.ipc : a.B * a.chunks_per_item;
   // enough K slices to fill the chip (~8 workgroups of the small tile / ~4 of the large one per CU), each at least 8 staged steps long
-  const int want = big ? 1024 : 2048;
+  const char* we2 = getenv("DMEL_WGRAD_WANT");
+  const int want = we2 ? atoi(we2) : (big ? 1024 : 2048);
   int slices = std::max(1, std::min((want + tiles - 1) / tiles, (total + 7) / 8));
   slices = std::min(slices, 65535 / a.taps);
   a.slices = slices;
@@ -368,10 +663,14 @@ static void launch_wgrad_any(WgArgs a, hipStream_t st) {
   else if (!split) hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
   else if (big && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 2, 2, 32>), grid, dim3(256), 0, st, a);
   else if (big) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 2, 2, 32>), grid, dim3(256), 0, st, a);
+  else if (f16 && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64, 2>), grid, dim3(256), 0, st, a);
+  else if (f16) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1, 1, 64, 2>), grid, dim3(256), 0, st, a);
   else if (bf16 && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64, 1>), grid, dim3(256), 0, st, a);
   else if (bf16) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1, 1, 64, 1>), grid, dim3(256), 0, st, a);
   else if (a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1, 1, 64>), grid, dim3(256), 0, st, a);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
 }
 
 // db[co] = sum over (b, t).  grid (Cout, splits): a workgroup reduces every splits-th 2048-sample piece of its channel's (b, t) plane
@@ -418,9 +717,8 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * taps * sizeof(float), st));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Cout * Cin * taps, 0.0);
-    launch_wgrad_any(a, st);
+    DMEL_TRY(launch_wgrad_any(a, st));
   }
-  DMEL_HIP(hipGetLastError());
   if (db) DMEL_TRY(launch_bgrad(dy, db, Cout, B, (int)T, st));
   return DMEL_OK;
 }
@@ -438,9 +736,8 @@ int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, i
   a.xstride = xstride; a.xoff = xoff; a.Tx = (int)Tx; a.taps_out = taps_out; a.tap_out = tap_out;
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols * taps, 0.0);
-    launch_wgrad_any(a, st);
+    DMEL_TRY(launch_wgrad_any(a, st));
   }
-  DMEL_HIP(hipGetLastError());
   return DMEL_OK;
 }
 

@@ -603,6 +603,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   if (!conv_block_coords(a, tile_n, mblk, b)) return;
   const int q0 = tile_n * BN;
   const int lb = b / a.len_div;
+  // (Round 2, fp16-split kernel: waves in odd SIMD slots sleeping 256-2048 cycles before the K loop -- to put the two workgroups of a CU out of
+  // phase -- changed nothing either: 0 +- 3 % on every shape.)
   // (Delaying the workgroups that land in odd wave slots -- so that a CU's two workgroups alternate between their MFMA loop and their
   // HBM-bound epilogue instead of doing both in phase -- was measured with 20 k / 50 k / 100 k cycle delays: 3-40 % slower on every
   // shape when applied to every such workgroup, no gain beyond the +-10 % run-to-run noise when applied to the first round only.

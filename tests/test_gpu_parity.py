@@ -706,6 +706,39 @@ def test_f16_split_conv_over_the_magnitude_range(dev, scale):
         L.dmel_conv_destroy(h)
 
 
+@pytest.mark.parametrize("dy_scale", [1e-12, 1e-7, 1e-3, 1.0, 1e4])
+@pytest.mark.parametrize("Cout,Cin,k,dil,T,B", [(64, 48, 7, 3, 1000, 2), (128, 96, 3, 1, 515, 3)])
+def test_conv_weight_gradient_fp16_split_at_any_gradient_magnitude(dev, Cout, Cin, k, dil, T, B, dy_scale):
+    """Rows of >= 256 samples take the fp16-split weight-gradient kernel (conv_bwd.hip): dy is staged x 2^(13 - exponent of max |dy|), found by a
+    reduction on the same stream, so the result is fp32-grade whatever the size of the gradients -- including entries eight decades below
+    the largest one."""
+    from dmel_codec_amd import _lib
+    torch.manual_seed(Cout + Cin + T)
+    w = torch.randn(Cout, Cin, k) / math.sqrt(Cin * k)
+    x = torch.randn(B, Cin, T)
+    dy = torch.randn(B, Cout, T) * dy_scale * torch.logspace(-8, 0, Cout)[None, :, None]      # rows spanning eight decades
+    w64, x64 = w.double().requires_grad_(), x.double().requires_grad_()
+    F.conv1d(x64, w64, None, dilation=dil, padding=dil * (k - 1) // 2).backward(dy.double())
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), None, Cout, Cin, k, dil))
+    try:
+        xd, dyd = x.to(dev), dy.to(dev)
+        dw = torch.full((Cout, Cin, k), float("nan"), device=dev)
+        db = torch.full((Cout,), float("nan"), device=dev)
+        _lib.check(L.dmel_conv_backward_weight(h, xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), db.data_ptr(), B, T, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        ref = w64.grad
+        assert rel_err(dw, ref) < 2e-6
+        # row by row: the small rows are exact relative to THEIR OWN size down to 2^-28 of the largest gradient (here 1e-8 of it: the smallest row
+        # sits at the edge and is allowed 1e-4; from 1e-6 of the maximum upwards fp32-grade)
+        for co in range(0, Cout, 7):
+            bar = 2e-6 if co >= Cout // 4 else 1e-4
+            assert rel_err(dw[co], ref[co]) < bar, (co, rel_err(dw[co], ref[co]))
+    finally:
+        L.dmel_conv_destroy(h)
+
+
 # ------------------------------------------------------------------------------------ conv backward (training path, first piece)
 @pytest.mark.parametrize("Cout,Cin,k,dil,T,B", [
     (32, 32, 3, 1, 100, 2), (64, 48, 7, 3, 257, 2), (140, 70, 3, 4, 93, 5), (70, 140, 1, 1, 93, 5), (128, 128, 11, 5, 700, 1),
