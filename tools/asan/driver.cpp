@@ -201,14 +201,14 @@ static void bigvgan(int n_up, const int* rates, const int* ks, int C0, int mels,
 int main() {
   // single convolutions: ragged channel counts, every tap count / dilation of the vocoder, forward + both backward entry points
   const int shapes[][6] = {{256, 256, 7, 3, 736, 2}, {128, 128, 11, 5, 3000, 1}, {1120, 560, 3, 2, 92, 2}, {70, 10, 1, 1, 93, 5}, {33, 17, 3, 1, 50, 1},
-                           {32, 32, 3, 1, 23552, 1}, {100, 560, 1, 1, 92, 3}};
+                           {32, 32, 3, 1, 23552, 1}, {100, 560, 1, 1, 92, 3}, {128, 64, 9, 1, 4592, 2}, {96, 80, 3, 1, 700, 2}};
   for (auto& s : shapes) {
     const int Cout = s[0], Cin = s[1], k = s[2], dil = s[3], T = s[4], B = s[5];
     std::vector<float> w((size_t)Cout * Cin * k, 0.01f), b(Cout, 0.1f);
     dmel_conv* c = nullptr;
     CK(dmel_conv_create(&c, w.data(), b.data(), Cout, Cin, k, dil));
     auto x = buf((size_t)B * Cin * T), y = buf((size_t)B * Cout * T), dw = buf((size_t)Cout * Cin * k), db = buf(Cout);
-    for (int prec : {DMEL_PRECISION_FP32, DMEL_PRECISION_BF16, DMEL_PRECISION_FP32_MFMA}) {
+    for (int prec : {DMEL_PRECISION_FP32, DMEL_PRECISION_BF16, DMEL_PRECISION_FP32_MFMA, DMEL_PRECISION_FP32_F16X2, DMEL_PRECISION_FP32_BF16X3}) {
       CK(dmel_conv_set_precision(c, prec));
       CK(dmel_conv_forward(c, x.data(), y.data(), B, T, nullptr));
     }
