@@ -67,6 +67,9 @@ struct SegRun {
   const int64_t* in_len = nullptr;
   float in_scale = 1.f;
   int64_t tshift = 0;      // output column q reads input column (q + tshift) * tstride + ...: a launch over a sub-range of a longer row
+  // fp16-split launches over a GRADIENT tensor (single segment): bit pattern of its max |value| in device memory (launch_absmax on the same
+  // stream); the kernel stages x * 2^(13 - exponent) instead of x * 2^-6 and undoes it on the accumulators.  nullptr: activations.
+  const uint32_t* in_absmax = nullptr;
 };
 
 struct ConvRun {

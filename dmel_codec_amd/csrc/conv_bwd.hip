@@ -576,29 +576,34 @@ static bool wgrad_big_tile() {
   static const bool v = [] { const char* e = getenv("DMEL_WGRAD_TILE128"); return e && e[0] == '1'; }();
   return v;
 }
+int launch_absmax(const float* v, int64_t n, hipStream_t st, const uint32_t** out) {
+  // a ring of device words: launches of one thread are ordered on their stream; the ring keeps earlier launches' words alive while later
+  // ones are queued
+  static thread_local DevBuf ring;
+  static thread_local unsigned next = 0;
+  constexpr unsigned kSlots = 1024;
+  if (!ring.p) {
+    DMEL_HIP(hipMalloc(&ring.p, kSlots * sizeof(uint32_t)));
+    ring.bytes = kSlots * sizeof(uint32_t);
+  }
+  uint32_t* slot = ring.as<uint32_t>() + (next++ % kSlots);
+  DMEL_HIP(hipMemsetAsync(slot, 0, sizeof(uint32_t), st));
+  const unsigned blocks = (unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 512);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, v, n, slot);
+  DMEL_HIP(hipGetLastError());
+  *out = slot;
+  return DMEL_OK;
+}
+
 // picks the kernel, then the K slicing for its tile and step (a: everything but chunks_per_item / ipc / slices / chunks_per_slice)
 static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.ipc = a.T <= 32 ? kWgK / a.T : 1;
   // short rows are mostly boundary steps (scalar loads in the split kernel): they stay on the fp32-MFMA kernel
   const bool split = a.ipc == 1 && !wgrad_native_only() && a.xstride <= 2 && a.T >= 256;
-  a.dy_absmax = nullptr;
   if (split && train_precision_override() != DMEL_PRECISION_BF16) {
-    // scale of the fp16 split: max |dy| of this launch, reduced on the same stream into one of a ring of device words (launches of one
-    // thread are ordered on their stream; the ring keeps earlier launches' words alive while later ones are queued)
-    static thread_local DevBuf ring;
-    static thread_local unsigned next = 0;
-    constexpr unsigned kSlots = 1024;
-    if (!ring.p) {
-      DMEL_HIP(hipMalloc(&ring.p, kSlots * sizeof(uint32_t)));
-      ring.bytes = kSlots * sizeof(uint32_t);
-    }
-    uint32_t* slot = ring.as<uint32_t>() + (next++ % kSlots);
-    DMEL_HIP(hipMemsetAsync(slot, 0, sizeof(uint32_t), st));
-    const int64_t n = (int64_t)a.B * a.Cout * a.T;
-    const unsigned blocks = (unsigned)std::min<int64_t>((n / 4 + 255) / 256 + 1, 512);
-    hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, a.dy, n, slot);
-    DMEL_HIP(hipGetLastError());
-    a.dy_absmax = slot;
+    if (!a.dy_absmax) DMEL_TRY(launch_absmax(a.dy, (int64_t)a.B * a.Cout * a.T, st, &a.dy_absmax));
+  } else {
+    a.dy_absmax = nullptr;
   }
   // bf16 training mode (TrainPrecisionScope): long rows take the one-piece instantiation of the split kernel; short rows (the 92-frame
   // WaveNet GEMMs, packed image rows) stay on the exact fp32-MFMA kernel, which is at least as accurate
@@ -714,6 +719,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   a.dy = dy; a.x = x; a.dw = dw;
   a.Cout = Cout; a.Cin = Cin; a.taps = taps; a.dil = dil; a.pad = dil * (taps - 1) / 2; a.B = B; a.T = (int)T;
   a.xstride = 1; a.xoff = 0; a.Tx = (int)T; a.taps_out = taps; a.tap_out = 0;
+  a.dy_absmax = nullptr; a.partial = nullptr;
   DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * taps * sizeof(float), st));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Cout * Cin * taps, 0.0);
@@ -726,7 +732,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
 // One tap of a stride-s convolution / transposed convolution: dw[(r * Ccols + c) * taps_out + tap_out] (+)= sum_{b,t} rows[b, r, t] *
 // cols[b, c, t * xstride + xoff]; rows (B, Crows, T), cols (B, Ccols, Tx).  The caller zeroes dw once before the taps.
 int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, int Crows, int Ccols, int xstride, int xoff, int64_t T,
-                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t st, int taps) {
+                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t st, int taps, const uint32_t* rows_absmax) {
   DMEL_CHECK_ARG(rows && cols && dw, "conv_wgrad_strided: NULL argument");
   DMEL_CHECK_ARG(B > 0 && T > 0 && Tx > 0 && Tx < ((int64_t)1 << 30) && Crows > 0 && Ccols > 0 && xstride > 0 && taps_out > 0 &&
                      tap_out >= 0 && taps > 0 && tap_out + taps <= taps_out, "conv_wgrad_strided: bad shape");
@@ -734,6 +740,7 @@ int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, i
   a.dy = rows; a.x = cols; a.dw = dw;
   a.Cout = Crows; a.Cin = Ccols; a.taps = taps; a.dil = 1; a.pad = 0; a.B = B; a.T = (int)T;
   a.xstride = xstride; a.xoff = xoff; a.Tx = (int)Tx; a.taps_out = taps_out; a.tap_out = tap_out;
+  a.dy_absmax = rows_absmax; a.partial = nullptr;
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Crows * Ccols * taps, 0.0);
     DMEL_TRY(launch_wgrad_any(a, st));

@@ -31,6 +31,7 @@ struct SegArgs {
   const int64_t* in_len;
   float in_scale;
   int Cin, nchunk, taps, dil, pad_left, tstride, toff;
+  const uint32_t* in_absmax;    // fp16 split over a gradient tensor (segment 0 only): see conv.h SegRun
 };
 
 struct KArgs {
@@ -579,7 +580,7 @@ __device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {      // {bf1
 // allocator still parks one weight set on the B-fragment registers; the default register budget stays.)
 template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO, int NP, int KG>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_bf16_kernel(KArgs a) {
-  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32, NTHR = 64 * WAVES_M * WAVES_N;
+  constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   constexpr int XS = BN + HALO;
   constexpr int SUB = KG / 2;                            // 16-channel K steps (per tap) per staged chunk
   // Staging map: an item is (8-channel group kg, column j) -- eight channels of one staged column, i.e. one lane's B operand.  The group is
@@ -656,6 +657,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   // load_x only issues loads (clamped addresses, no predication, no use of the values): validity is applied by store_x,
   // a K step of MFMAs later, so no s_waitcnt lands between the loads and the math.  Addresses are a scalar base (batch
   // item) plus one unsigned 32-bit byte offset per lane: row offsets advance by additions, clamped to the last channel.
+  // NP = 2 over a gradient tensor: staged x 2^(13 - e), e = exponent of the tensor's max |value| (the largest gradient lands in [2^13, 2^14),
+  // everything within 2^-27 of it keeps 2^-24 relative precision), instead of the fixed 2^-6 of activations; undone on the accumulators
+  float f16_in = kF16XScale, f16_out = 1.f;
+  if (NP == 2 && a.seg[0].in_absmax) {
+    const int e = min(max((int)(*a.seg[0].in_absmax >> 23) - 127, -100), 100);
+    f16_in = __uint_as_float((uint32_t)(127 + 13 - e) << 23);
+    f16_out = __uint_as_float((uint32_t)(127 - 13 + e) << 23) * (1.f / kF16WScale);
+  }
   bool xok[NIT];
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int st_kg0 = (wave_u / SEG) * RPW, st_j0 = (wave_u % SEG) * SL;
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     // No contraction in here: the scaled input is ROUNDED to fp32 and then split.  Fused into the first subtraction of the split (fma), the
     // pieces would sum to the unrounded product, and the whole-stack WaveNet kernel, which rounds, would differ in the last bit.
 #pragma clang fp contract(off)
-    const float scale = NP == 2 ? a.seg[sg].in_scale * kF16XScale : a.seg[sg].in_scale;
+    const float scale = NP == 2 ? a.seg[sg].in_scale * f16_in : a.seg[sg].in_scale;
     const int Cin = a.seg[sg].Cin;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -862,7 +871,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaf(acl[mi][ni][r], 1.f / kF16LoScale, acc[mi][ni][r]);
+        for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaf(acl[mi][ni][r], 1.f / kF16LoScale, acc[mi][ni][r]) * f16_out;
   }
   if ((DMEL_EXP & 8) && acc[0][0][0] != 12345.f) return;
   conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
@@ -1023,6 +1032,7 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
                    "conv: taps>1 with strided input is unsupported by the native fp32-MFMA kernel");
     o.x = r.seg[s].x; o.bstride = r.seg[s].bstride; o.cstride = r.seg[s].cstride; o.Tin = r.seg[s].Tin;
     o.in_len = r.seg[s].in_len; o.in_scale = r.seg[s].in_scale;
+    o.in_absmax = (s == 0 && d.nseg == 1 && r.precision == DMEL_PRECISION_FP32_F16X2) ? r.seg[s].in_absmax : nullptr;
     o.Cin = sd.Cin; o.nchunk = (sd.Cin + kCK - 1) / kCK; o.taps = sd.taps; o.dil = sd.dil;
     o.pad_left = sd.pad_left; o.tstride = sd.tstride; o.toff = sd.toff + (int)(r.seg[s].tshift * sd.tstride);
     max_halo = std::max(max_halo, (sd.taps - 1) * sd.dil);

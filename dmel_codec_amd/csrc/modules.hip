@@ -2055,12 +2055,15 @@ extern "C" int dmel_discriminator_backward(const dmel_discriminator* d, const fl
                          (int)p.W[i + 1]);
       DMEL_HIP(hipGetLastError());
     }
-    // bias and weight gradients: one launch per kernel row, the kw horizontal taps on the grid
+    // bias and weight gradients: one launch per kernel row, the kw horizontal taps on the grid.  The fp16-split kernels that read g (the
+    // weight gradients and, below, backward-data) scale it by its max, found once per layer.
     DMEL_TRY(launch_conv_bgrad(g, grads + d->slot_of(pk + "bias"), l.Cout, B, Tout, st));
     DMEL_HIP(hipMemsetAsync(t.dwfold, 0, (size_t)l.Cout * l.Cin * 3 * l.kw * sizeof(float), st));
+    const uint32_t* g_absmax = nullptr;
+    if (train_precision_override() != DMEL_PRECISION_BF16) DMEL_TRY(launch_absmax(g, (int64_t)B * l.Cout * Tout, st, &g_absmax));
     for (int dh = 0; dh < 3; ++dh)
       DMEL_TRY(launch_conv_wgrad_strided(g, p.act[i] + (int64_t)(dh - 1) * p.P[i], t.dwfold, l.Cout, l.Cin, l.sw, -l.pw, Tout, Tin, 3 * l.kw,
-                                         dh * l.kw, B, st, l.kw));
+                                         dh * l.kw, B, st, l.kw, g_absmax));
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((unsigned)l.Cout), dim3(256), 0, st, t.dwfold, l.v_dev.as<float>(), l.g_dev.as<float>(),
                        grads + d->slot_of(pk + "parametrizations.weight.original0"),
                        grads + d->slot_of(pk + "parametrizations.weight.original1"), (int64_t)l.Cin * 3 * l.kw);
@@ -2075,6 +2078,8 @@ extern "C" int dmel_discriminator_backward(const dmel_discriminator* d, const fl
       for (int ph = 0; ph < nph; ++ph) {
         ConvRun r = run_1seg(g - (int64_t)(dh - 1) * p.P[i + 1], l.Cout, Tout, dst, l.Cin, Tin, B);
         r.accumulate = k > 0;
+        static const bool dgrad_f16 = [] { const char* e = getenv("DMEL_DGRAD_F16X2"); return !(e && e[0] == '0'); }();
+        if (g_absmax && dgrad_f16) { r.precision = DMEL_PRECISION_FP32_F16X2; r.seg[0].in_absmax = g_absmax; }
         if (l.sw == 2) {
           r.out_tstride = 2; r.phase_base = ph; r.Tcols = Tin / 2; r.Tout = Tin;
         }

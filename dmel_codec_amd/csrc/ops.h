@@ -81,8 +81,12 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
                       hipStream_t s);
 // `taps` adjacent taps of a strided (transposed) conv:
 //   dw[(r*Ccols + c)*taps_out + tap_out + k] += sum_{b,t} rows[b,r,t] * cols[b,c,t*xstride + xoff + k],  k < taps
+// rows_absmax: the bit pattern of max |rows| if the caller already has it (launch_absmax), else nullptr (reduced inside when needed)
 int launch_conv_wgrad_strided(const float* rows, const float* cols, float* dw, int Crows, int Ccols, int xstride, int xoff, int64_t T,
-                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t s, int taps = 1);
+                              int64_t Tx, int taps_out, int tap_out, int B, hipStream_t s, int taps = 1, const uint32_t* rows_absmax = nullptr);
+// max |v| over n floats, as a bit pattern, into a device word owned by the library (a ring of words per host thread): the scale of the
+// fp16-split kernels that read gradient tensors.  Runs on `s`; *slot stays valid for the next ~1000 calls of this thread.
+int launch_absmax(const float* v, int64_t n, hipStream_t s, const uint32_t** slot);
 int launch_conv_bgrad(const float* dy, float* db, int Cout, int B, int64_t T, hipStream_t s);
 
 }  // namespace dmel
