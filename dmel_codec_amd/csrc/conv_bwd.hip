@@ -43,7 +43,10 @@ struct WgArgs {
 };
 
 // grid (ceil(Cin/64), ceil(Cout/64), taps * slices); 256 threads = 2 x 2 waves of 32 x 32
-template <bool PACK>      // PACK: several short batch items per staged step (per-lane item index); otherwise the item is wave-uniform
+// PACK = 1: several short batch items per staged step (per-lane item index).  PACK = 2: the reduction runs over the FLATTENED sample index
+// n = b * T + t in steps of 64, whatever T is (a 92-frame row wastes 30 % of its second 64-sample step otherwise): lane -> (n / T, n % T).
+// PACK = 0: the item is wave-uniform.
+template <int PACK>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   __shared__ __attribute__((aligned(16))) float dys[kWgTile * kWgPitch];
   __shared__ __attribute__((aligned(16))) float xs[kWgTile * kWgPitch];
@@ -56,10 +59,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  const int total = PACK ? (a.B + a.ipc - 1) / a.ipc : a.B * a.chunks_per_item;
+  const int total = PACK == 1 ? (a.B + a.ipc - 1) / a.ipc : PACK == 2 ? (a.B * a.T + kWgK - 1) / kWgK : a.B * a.chunks_per_item;
   const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
   const int r31 = lane & 31, h = lane >> 5;
-  const int lane_item = PACK ? lane / a.T : 0, lane_t = PACK ? lane - lane_item * a.T : lane;
+  const int lane_item = PACK == 1 ? lane / a.T : 0, lane_t = PACK == 1 ? lane - lane_item * a.T : lane;
   // global loads of step c into registers (clamped addresses, validity kept as bit masks and applied when the values are staged):
   // they are issued before the MFMA loop of step c - 1, so their latency hides behind it
   float vd[16], vx[16];
@@ -67,10 +70,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
   auto fetch = [&](int c) {
     int b, t0;
     bool lane_ok = true;
-    if (PACK) {                          // c indexes groups of ipc items; every lane has its own item
+    if (PACK == 1) {                     // c indexes groups of ipc items; every lane has its own item
       b = c * a.ipc + lane_item;
       t0 = 0;
       lane_ok = lane_item < a.ipc && b < a.B;
+      b = min(b, a.B - 1);
+    } else if (PACK == 2) {              // c indexes 64 flattened samples
+      const int n = c * kWgK + lane;
+      b = n / a.T;
+      t0 = n - b * a.T - lane_t;         // so that t below is n % T
+      lane_ok = b < a.B;
       b = min(b, a.B - 1);
     } else {
       b = c / a.chunks_per_item;
@@ -600,16 +609,19 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.ipc = a.T <= 32 ? kWgK / a.T : 1;
   // short rows are mostly boundary steps (scalar loads in the split kernel): they stay on the fp32-MFMA kernel
   const bool split = a.ipc == 1 && !wgrad_native_only() && a.xstride <= 2 && a.T >= 256;
-  if (split && train_precision_override() != DMEL_PRECISION_BF16) {
+  // the three-tap kernel also serves the bf16 training mode (its fp16 split is more accurate than bf16 operands and, without atomics, faster)
+  const bool can_group = split && a.dil == 1 && a.taps % 3 == 0;
+  if (split && (train_precision_override() != DMEL_PRECISION_BF16 || can_group)) {
     if (!a.dy_absmax) DMEL_TRY(launch_absmax(a.dy, (int64_t)a.B * a.Cout * a.T, st, &a.dy_absmax));
   } else {
     a.dy_absmax = nullptr;
   }
   // bf16 training mode (TrainPrecisionScope): long rows take the one-piece instantiation of the split kernel; short rows (the 92-frame
   // WaveNet GEMMs, packed image rows) stay on the exact fp32-MFMA kernel, which is at least as accurate
-  const bool bf16 = split && train_precision_override() == DMEL_PRECISION_BF16;
-  // fp32 mode: long rows take the fp16-split instantiation (three products, cheaper operand conversion; DMEL_WGRAD_F16X2=0: the six-product one)
+  static const bool group_off0 = [] { const char* e = getenv("DMEL_WGRAD_TAPGROUP"); return e && e[0] == '0'; }();
   static const bool f16_off = [] { const char* e = getenv("DMEL_WGRAD_F16X2"); return e && e[0] == '0'; }();
+  const bool bf16 = split && train_precision_override() == DMEL_PRECISION_BF16 && !(can_group && !group_off0 && !f16_off && a.dy_absmax);
+  // fp32 mode: long rows take the fp16-split instantiation (three products, cheaper operand conversion; DMEL_WGRAD_F16X2=0: the six-product one)
   const bool f16 = split && !bf16 && !f16_off && a.dy_absmax != nullptr;
   static const bool group_off = [] { const char* e = getenv("DMEL_WGRAD_TAPGROUP"); return e && e[0] == '0'; }();
   const bool grouped = f16 && !group_off && a.dil == 1 && a.taps % 3 == 0;
@@ -655,7 +667,10 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.chunks_per_item = (a.T + ks - 1) / ks;
   const int tm = (a.Cout + tile - 1) / tile, tn = (a.Cin + tile - 1) / tile;
   const int tiles = tm * tn * a.taps;
-  const int total = a.ipc > 1 ? (a.B + a.ipc - 1) / a.ipc : a.B * a.chunks_per_item;
+  // rows of 33..255 samples whose last 64-sample step would be mostly padding (T = 92: 30 % of the MFMA work) reduce over the flattened index
+  const bool flat = !split && a.ipc == 1 && a.T < 256 && (int64_t)a.B * a.T < ((int64_t)1 << 30) &&
+                    a.chunks_per_item * kWgK * 10 > a.T * 11 && !getenv("DMEL_WGRAD_NOFLAT");
+  const int total = a.ipc > 1 ? (a.B + a.ipc - 1) / a.ipc : flat ? (a.B * a.T + kWgK - 1) / kWgK : a.B * a.chunks_per_item;
   // enough K slices to fill the chip (~8 workgroups of the small tile / ~4 of the large one per CU), each at least 8 staged steps long
   const char* we2 = getenv("DMEL_WGRAD_WANT");
   const int want = we2 ? atoi(we2) : (big ? 1024 : 2048);
@@ -664,8 +679,9 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.slices = slices;
   a.chunks_per_slice = (total + slices - 1) / slices;
   const dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)(a.taps * slices));
-  if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<true>, grid, dim3(256), 0, st, a);
-  else if (!split) hipLaunchKernelGGL(conv_wgrad_kernel<false>, grid, dim3(256), 0, st, a);
+  if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  else if (flat) hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, a);
+  else if (!split) hipLaunchKernelGGL(conv_wgrad_kernel<0>, grid, dim3(256), 0, st, a);
   else if (big && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 2, 2, 32>), grid, dim3(256), 0, st, a);
   else if (big) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 2, 2, 32>), grid, dim3(256), 0, st, a);
   else if (f16 && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64, 2>), grid, dim3(256), 0, st, a);

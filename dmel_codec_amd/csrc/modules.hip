@@ -2060,7 +2060,7 @@ extern "C" int dmel_discriminator_backward(const dmel_discriminator* d, const fl
     DMEL_TRY(launch_conv_bgrad(g, grads + d->slot_of(pk + "bias"), l.Cout, B, Tout, st));
     DMEL_HIP(hipMemsetAsync(t.dwfold, 0, (size_t)l.Cout * l.Cin * 3 * l.kw * sizeof(float), st));
     const uint32_t* g_absmax = nullptr;
-    if (train_precision_override() != DMEL_PRECISION_BF16) DMEL_TRY(launch_absmax(g, (int64_t)B * l.Cout * Tout, st, &g_absmax));
+    DMEL_TRY(launch_absmax(g, (int64_t)B * l.Cout * Tout, st, &g_absmax));
     for (int dh = 0; dh < 3; ++dh)
       DMEL_TRY(launch_conv_wgrad_strided(g, p.act[i] + (int64_t)(dh - 1) * p.P[i], t.dwfold, l.Cout, l.Cin, l.sw, -l.pw, Tout, Tin, 3 * l.kw,
                                          dh * l.kw, B, st, l.kw, g_absmax));
