@@ -27,7 +27,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", default="")
-    ap.add_argument("--precision", type=int, default=0, help="0 fp32 (split-bf16 kernel), 1 bf16 operands, 2 fp32 on the native fp32 MFMA")
+    ap.add_argument("--precision", type=int, default=0, help="0 fp32 (six-product bf16 split), 1 bf16 operands, 2 fp32 on the native fp32 MFMA, 3 fp32 from the three-product fp16 split")
     ap.add_argument("--check", action="store_true", help="compare with torch conv1d (operands rounded the same way)")
     args = ap.parse_args()
     L = _lib.lib()

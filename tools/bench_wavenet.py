@@ -15,6 +15,7 @@ ap.add_argument("--batch", type=int, default=32)
 ap.add_argument("--frames", type=int, default=92)
 ap.add_argument("--groups", type=int, default=8)
 ap.add_argument("--reps", type=int, default=30)
+ap.add_argument("--precision", default=None, help="fp32 (six-product split) | fp32_f16x2 (what VQGAN asks of its decoder); default: f16x2 for dec, fp32 for enc")
 args = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -33,6 +34,7 @@ else:
     x = torch.randn(N, 10, args.frames, device=dev)
     c = None
     flops = 2.0 * N * args.frames * (10 * 70 + 20 * (140 * 210 + 140 * 70) + 70 * 70)
+m.set_precision(args.precision or ("fp32_f16x2" if args.which == "dec" else "fp32"))
 for _ in range(3):
     y = m(x, condition=c)
 torch.cuda.synchronize()
