@@ -128,6 +128,11 @@ PROTOTYPES = {
     "dmel_conv_create": (C.c_int, [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dmel_conv_destroy": (None, [vp]),
     "dmel_conv_set_precision": (C.c_int, [vp, C.c_int]),
+    "dmel_conv_transpose1d_create": (C.c_int, [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dmel_conv_transpose1d_destroy": (None, [vp]),
+    "dmel_conv_transpose1d_set_precision": (C.c_int, [vp, C.c_int]),
+    "dmel_conv_transpose1d_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
+    "dmel_conv_post_f32": (C.c_int, [vp, vp, C.c_float, C.c_int, vp, C.c_int, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_conv_backward_data": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_conv_backward_weight": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_conv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),

@@ -2110,7 +2110,74 @@ struct UpStage {
   int u, k, Cin, Cout;
   PackedConv lo, hi;          // phases [0,u/2) with taps d={-1,0}; phases [u/2,u) with taps d={0,+1}
 };
+// ConvTranspose1d(Cin, Cout, k = 2u, stride u, padding u/2) as two groups of u/2 phase sub-convolutions with two taps each:
+//   y[co, u q + ph] = sum_ci sum_d W[ci, co, ph + u/2 - u d] x[ci, q + d]                    (bigvgan.py:320-334, :371-374)
+// w: (Cin, Cout, k) host floats, bias: Cout host floats.  us.u / k / Cin / Cout are set by the caller.
+int pack_up_stage(UpStage& us, const float* w, const float* bias) {
+  const int u = us.u, k = us.k, hu = u / 2, Co = us.Cout;
+  for (int half = 0; half < 2; ++half) {
+    PackDesc d;
+    d.mode = EPI_LINEAR; d.nseg = 1; d.C = Co; d.phases = hu;
+    d.seg[0].Cin = us.Cin; d.seg[0].taps = 2; d.seg[0].dil = 1; d.seg[0].pad_left = half == 0 ? 1 : 0;
+    DMEL_TRY(pack_conv(half == 0 ? us.lo : us.hi, d,
+                       [&](int, int row, int ci, int tap) {
+                         const int ph = row / Co + half * hu, co = row % Co;
+                         const int dd = tap - (half == 0 ? 1 : 0);
+                         const int kk = ph + hu - u * dd;
+                         return (kk >= 0 && kk < k) ? w[((size_t)ci * Co + co) * k + kk] : 0.f;
+                       },
+                       [&](int row) { return bias ? bias[row % Co] : 0.f; }));
+  }
+  return DMEL_OK;
+}
+// x (B, Cin, T) -> y (B, Cout, u T)
+int launch_up_stage(const UpStage& us, const float* x, float* y, int B, int64_t T, int precision, hipStream_t st) {
+  for (int half = 0; half < 2; ++half) {
+    ConvRun r = run_1seg(x, us.Cin, T, y, us.Cout, T * us.u, B);
+    r.Tcols = T; r.out_tstride = us.u; r.phase_base = half * (us.u / 2); r.Tout = T * us.u;
+    r.precision = precision;
+    DMEL_TRY(launch_conv(half == 0 ? us.lo : us.hi, r, st));
+  }
+  return DMEL_OK;
+}
 }  // namespace
+
+// ---- standalone transposed convolution / output convolution (C-ABI rows convT1d, conv_post of SURVEY section 8(b)) ---------------
+struct dmel_conv_transpose {
+  UpStage us;
+  int precision = 0;
+};
+extern "C" int dmel_conv_transpose1d_create(dmel_conv_transpose** out, const float* w_host, const float* bias_host, int Cin, int Cout, int k,
+                                            int stride) {
+  DMEL_CHECK_ARG(out && w_host, "conv_transpose1d_create: NULL argument");
+  DMEL_CHECK_ARG(Cin > 0 && Cout > 0 && stride >= 2 && (stride % 2) == 0, "conv_transpose1d_create: bad shape (even stride >= 2 required)");
+  if (k != 2 * stride) {
+    set_error("conv_transpose1d: only k == 2 * stride with padding stride / 2 (every BigVGAN up-sampler) is built, got k %d stride %d", k, stride);
+    return DMEL_EUNSUPPORTED;
+  }
+  auto* h = new dmel_conv_transpose();
+  h->us.u = stride; h->us.k = k; h->us.Cin = Cin; h->us.Cout = Cout;
+  const int rc = pack_up_stage(h->us, w_host, bias_host);
+  if (rc != DMEL_OK) { delete h; return rc; }
+  *out = h;
+  return DMEL_OK;
+}
+extern "C" void dmel_conv_transpose1d_destroy(dmel_conv_transpose* h) { delete h; }
+extern "C" int dmel_conv_transpose1d_set_precision(dmel_conv_transpose* h, int precision) {
+  DMEL_CHECK_ARG(h && valid_precision(precision), "conv_transpose1d_set_precision: not a DMEL_PRECISION_* value");
+  h->precision = precision;
+  return DMEL_OK;
+}
+extern "C" int dmel_conv_transpose1d_forward(const dmel_conv_transpose* h, const float* x, float* y, int B, int64_t T, void* stream) {
+  DMEL_CHECK_ARG(h && x && y, "conv_transpose1d_forward: NULL argument");
+  DMEL_CHECK_ARG(B > 0 && T > 0, "conv_transpose1d_forward: bad shape");
+  return launch_up_stage(h->us, x, y, B, T, h->precision, (hipStream_t)stream);
+}
+extern "C" int dmel_conv_post_f32(const float* x, const float* w_dev, float bias, int act, float* y, int B, int C, int K, int64_t T, void* stream) {
+  DMEL_CHECK_ARG(x && w_dev && y, "conv_post: NULL argument");
+  DMEL_CHECK_ARG(act == 0 || act == 2 || act == 3, "conv_post: act must be 0 (none), 2 (tanh) or 3 (clamp to [-1, 1])");
+  return launch_conv_post(x, y, w_dev, bias, act == 0 ? ACT_NONE : act == 2 ? ACT_TANH : ACT_CLAMP1, B, C, K, T, (hipStream_t)stream);
+}
 
 struct dmel_bigvgan {
   dmel_bigvgan_config cfg;
@@ -2260,21 +2327,7 @@ extern "C" int dmel_bigvgan_finalize(dmel_bigvgan* m) {
     if (!m->ts.conv_weight(p, {us.Cin, us.Cout, us.k}, w)) return DMEL_EMISSING;
     const HostTensor* b = m->ts.need(p + "bias", {us.Cout});
     if (!b) return DMEL_EMISSING;
-    const int u = us.u, k = us.k, hu = u / 2, Co = us.Cout;
-    // y[co, u q + ph] = sum_ci sum_d W[ci, co, ph + u/2 - u d] x[ci, q + d]   (padding (k-u)/2 = u/2)
-    for (int half = 0; half < 2; ++half) {
-      PackDesc d;
-      d.mode = EPI_LINEAR; d.nseg = 1; d.C = Co; d.phases = hu;
-      d.seg[0].Cin = us.Cin; d.seg[0].taps = 2; d.seg[0].dil = 1; d.seg[0].pad_left = half == 0 ? 1 : 0;
-      DMEL_TRY(pack_conv(half == 0 ? us.lo : us.hi, d,
-                         [&](int, int row, int ci, int tap) {
-                           const int ph = row / Co + half * hu, co = row % Co;
-                           const int dd = tap - (half == 0 ? 1 : 0);
-                           const int kk = ph + hu - u * dd;
-                           return (kk >= 0 && kk < k) ? w[((size_t)ci * Co + co) * k + kk] : 0.f;
-                         },
-                         [&](int row) { return b->v[row % Co]; }));
-    }
+    DMEL_TRY(pack_up_stage(us, w.data(), b->v.data()));
     for (int j = 0; j < c.num_kernels; ++j) {
       AmpBlock& ab = m->blocks[(size_t)i * c.num_kernels + j];
       ab.k = c.resblock_kernel_sizes[j];
@@ -2378,12 +2431,7 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
   for (int i = 0; i < c.num_upsamples; ++i) {
     const UpStage& us = m->ups[i];
     const int64_t Tn = Tc * us.u;
-    for (int half = 0; half < 2; ++half) {  // transposed conv as two phase groups (bigvgan.py:371-374)
-      ConvRun r = run_1seg(x, us.Cin, Tc, xu, us.Cout, Tn, B);
-      r.Tcols = Tc; r.out_tstride = us.u; r.phase_base = half * (us.u / 2); r.Tout = Tn;
-      r.precision = prec;
-    DMEL_TRY(launch_conv(half == 0 ? us.lo : us.hi, r, st));
-    }
+    DMEL_TRY(launch_up_stage(us, x, xu, B, Tc, prec, st));  // transposed conv as two phase groups (bigvgan.py:371-374)
     ch = us.Cout;
     Tc = Tn;
     const int64_t bs = (int64_t)ch * Tc;

@@ -199,6 +199,73 @@ def _conv_backward(ctx, dy):
 conv1d_dilated.register_autograd(_conv_backward, setup_context=_conv_setup)
 
 
+# ----------------------------------------------------------------------------------------------------- transposed conv / output conv
+_convt_cache: dict = {}
+
+
+def _convt_handle(weight: Tensor, bias: Optional[Tensor], stride: int) -> int:
+    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), stride,
+           None if bias is None else (bias.data_ptr(), bias._version))
+    h = _convt_cache.get(key)
+    if h is None:
+        if len(_convt_cache) >= 32:
+            for old in _convt_cache.values():
+                _lib.lib().dmel_conv_transpose1d_destroy(old)
+            _convt_cache.clear()
+        Cin, Cout, k = weight.shape
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        b = bias.detach().to("cpu", torch.float32).contiguous() if bias is not None else None
+        hv = C.c_void_p()
+        _lib.check(_lib.lib().dmel_conv_transpose1d_create(C.byref(hv), w.data_ptr(), _lib.ptr(b), Cin, Cout, k, stride), "conv_transpose1d_create")
+        h = hv.value
+        _convt_cache[key] = h
+    return h
+
+
+@torch.library.custom_op("dmel_hip::conv_transpose1d", mutates_args=(), device_types="cuda")
+def conv_transpose1d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int) -> Tensor:
+    """F.conv_transpose1d(x, weight, bias, stride=stride, padding=(k - stride) // 2) for k == 2 * stride (every BigVGAN up-sampler,
+    bigvgan.py:320-334): `stride` phase sub-convolutions on the implicit-GEMM kernel.  weight (Cin, Cout, k), weight norm folded."""
+    _lib.require_cuda(x, "x")
+    x = x.float().contiguous()
+    B, Cin, T = x.shape
+    if weight.ndim != 3 or weight.shape[0] != Cin:
+        raise ValueError(f"weight must be ({Cin}, Cout, k), got {tuple(weight.shape)}")
+    y = torch.empty(B, weight.shape[1], T * stride, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        h = _convt_handle(weight, bias, stride)
+        _lib.check(_lib.lib().dmel_conv_transpose1d_forward(h, x.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()), "conv_transpose1d_forward")
+    return y
+
+
+@conv_transpose1d.register_fake
+def _(x, weight, bias, stride):
+    return x.new_empty((x.shape[0], weight.shape[1], x.shape[2] * stride), dtype=torch.float32)
+
+
+@torch.library.custom_op("dmel_hip::conv_post", mutates_args=(), device_types="cuda")
+def conv_post(x: Tensor, weight: Tensor, bias: float, activation: str) -> Tensor:
+    """The C -> 1 convolution that ends the vocoder (bigvgan.py:386-391): act(F.conv1d(x, weight (1, C, K), padding=K // 2) + bias),
+    activation "none" | "tanh" | "clamp"."""
+    _lib.require_cuda(x, "x")
+    x = x.float().contiguous()
+    B, Cc, T = x.shape
+    if weight.ndim != 3 or weight.shape[0] != 1 or weight.shape[1] != Cc or weight.shape[2] % 2 != 1:
+        raise ValueError(f"weight must be (1, {Cc}, odd K), got {tuple(weight.shape)}")
+    act = {"none": 0, "tanh": 2, "clamp": 3}[activation]
+    w = weight.detach().to(x.device, torch.float32).contiguous()
+    y = torch.empty(B, 1, T, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().dmel_conv_post_f32(x.data_ptr(), w.data_ptr(), float(bias), act, y.data_ptr(), B, Cc, weight.shape[2], T,
+                                                 _lib.stream_ptr()), "conv_post")
+    return y
+
+
+@conv_post.register_fake
+def _(x, weight, bias, activation):
+    return x.new_empty((x.shape[0], 1, x.shape[2]), dtype=torch.float32)
+
+
 # ----------------------------------------------------------------------------------------------------- STFT -> log-mel
 _plans: dict = {}
 

@@ -351,6 +351,22 @@ int dmel_conv_backward_data(dmel_conv* c, const float* dy, float* dx, int B, int
 int dmel_conv_backward_weight(const dmel_conv* c, const float* x, const float* dy, float* dw, float* db /*nullable*/, int B,
                               int64_t T, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Standalone transposed convolution and output convolution      (convT1d, conv_post)
+ * ConvTranspose1d(Cin, Cout, k = 2 * stride, stride, padding = stride / 2): every up-sampler of BigVGAN
+ * (models/modules/bigvgan/bigvgan.py:320-334, applied at :371-374), run as `stride` phase sub-convolutions on the implicit-GEMM
+ * kernel.  w_host (Cin, Cout, k) and bias_host (Cout, nullable) are HOST arrays in torch's ConvTranspose1d layout, weight norm
+ * already folded.  x (B, Cin, T) -> y (B, Cout, T * stride), device, fp32.  Other k / stride / padding: DMEL_EUNSUPPORTED.
+ * dmel_conv_post_f32: the C -> 1 convolution that ends the vocoder (bigvgan.py:386-391): y[b, 0, t] = act(bias + sum_{c,k} w[c, k]
+ * x[b, c, t + k - K/2]), act 0 none / 2 tanh / 3 clamp to [-1, 1]; w_dev (C, K) DEVICE floats, K odd, C * K * 4 <= 48 KB.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct dmel_conv_transpose dmel_conv_transpose;
+int dmel_conv_transpose1d_create(dmel_conv_transpose** out, const float* w_host, const float* bias_host, int Cin, int Cout, int k, int stride);
+void dmel_conv_transpose1d_destroy(dmel_conv_transpose* h);
+int dmel_conv_transpose1d_set_precision(dmel_conv_transpose* h, int precision);   /* DMEL_PRECISION_* */
+int dmel_conv_transpose1d_forward(const dmel_conv_transpose* h, const float* x, float* y, int B, int64_t T, void* stream);
+int dmel_conv_post_f32(const float* x, const float* w_dev, float bias, int act, float* y, int B, int C, int K, int64_t T, void* stream);
+
 /* Timing hook used by bench.py: when enabled, every launch of the named kernel family on `stream` is
  * bracketed by hipEvents; dmel_prof_read returns the launch count and total milliseconds since the last reset
  * (synchronises the events it reads).  family: "conv_igemm", "aa_snake", "stft_logmel", "small". */

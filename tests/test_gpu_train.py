@@ -216,6 +216,20 @@ def test_torch_ops_are_registered_and_match_the_oracle(dev):
     assert rel_err(yc, F.conv1d(xc64, w64, bb64, dilation=3, padding=9).detach()) < 2e-5
     yc.square().sum().backward()
     assert rel_err(xcd.grad, xc64.grad) < 2e-5 and rel_err(wd.grad, w64.grad) < 2e-5 and rel_err(bdv.grad, bb64.grad) < 2e-5
+    # --- conv_transpose1d (k = 2 * stride, padding stride / 2) and conv_post: the C-ABI rows convT1d / conv_post as ops
+    for stride, Ci, Co, Tt in ((8, 40, 24, 37), (2, 16, 8, 101), (4, 70, 33, 5)):
+        wt, bt = torch.randn(Ci, Co, 2 * stride, generator=g) / (Ci * 2) ** 0.5, torch.randn(Co, generator=g) * 0.1
+        xt = torch.randn(2, Ci, Tt, generator=g)
+        ref_t = F.conv_transpose1d(xt.double(), wt.double(), bt.double(), stride=stride, padding=stride // 2)
+        yt = ops.conv_transpose1d(xt.to(dev), wt.to(dev), bt.to(dev), stride)
+        assert yt.shape == ref_t.shape and rel_err(yt, ref_t) < 2e-6, (stride, rel_err(yt, ref_t))
+    with pytest.raises(RuntimeError, match="2 \\* stride"):
+        ops.conv_transpose1d(torch.randn(1, 4, 9, device=dev), torch.randn(4, 4, 3, device=dev), None, 2)
+    wp, xp = torch.randn(1, 32, 7, generator=g) * 0.05, torch.randn(3, 32, 500, generator=g)
+    for act, fn in (("none", lambda v: v), ("tanh", torch.tanh), ("clamp", lambda v: v.clamp(-1, 1))):
+        ref_p = fn(F.conv1d(xp.double(), wp.double(), torch.tensor([0.3], dtype=torch.float64), padding=3) * (4.0 if act == "clamp" else 1.0))
+        yp = ops.conv_post(xp.to(dev) * (4.0 if act == "clamp" else 1.0), wp.to(dev), 0.3 * (4.0 if act == "clamp" else 1.0), act)
+        assert yp.shape == (3, 1, 500) and rel_err(yp, ref_p) < 2e-6, act
     # --- stft_logmel
     audio = torch.randn(2, 24000, generator=g) * 0.1
     mel_ref = ref_cpu.stft_logmel(audio[:, None, :], 24000, 1024, 1024, 256, 80, 0.0, None)

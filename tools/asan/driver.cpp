@@ -242,6 +242,24 @@ int main() {
   { const int r[4] = {8, 8, 2, 2}, k[4] = {16, 16, 4, 4}; bigvgan(4, r, k, 512, 80, 1, true, 2, 12); }
   { const int r[2] = {4, 2}, k[2] = {8, 4}; bigvgan(2, r, k, 32, 20, 2, false, 2, 9); }
   { const int r[6] = {4, 4, 2, 2, 2, 2}, k[6] = {8, 8, 4, 4, 4, 4}; bigvgan(6, r, k, 96, 100, 1, true, 1, 3); }
+  {   // standalone transposed convolution / output convolution
+    for (int stride : {2, 8}) {
+      const int Ci = 40, Co = 24, k = 2 * stride, B = 2, T = 37;
+      std::vector<float> w((size_t)Ci * Co * k, 0.02f), b(Co, 0.1f);
+      dmel_conv_transpose* h = nullptr;
+      CK(dmel_conv_transpose1d_create(&h, w.data(), b.data(), Ci, Co, k, stride));
+      auto x = buf((size_t)B * Ci * T), y = buf((size_t)B * Co * T * stride);
+      for (int prec : {DMEL_PRECISION_FP32, DMEL_PRECISION_FP32_F16X2, DMEL_PRECISION_BF16}) {
+        CK(dmel_conv_transpose1d_set_precision(h, prec));
+        CK(dmel_conv_transpose1d_forward(h, x.data(), y.data(), B, T, nullptr));
+      }
+      dmel_conv_transpose1d_destroy(h);
+    }
+    dmel_conv_transpose* bad = nullptr;
+    if (dmel_conv_transpose1d_create(&bad, buf(64).data(), nullptr, 4, 4, 3, 2) == 0) { std::printf("FAIL conv_transpose1d accepted k != 2 stride\n"); ++failures; }
+    auto xp = buf(3 * 32 * 500), wp = buf(32 * 7), yp = buf(3 * 500);
+    CK(dmel_conv_post_f32(xp.data(), wp.data(), 0.3f, 2, yp.data(), 3, 32, 7, 500, nullptr));
+  }
   for (int nfft : {512, 1024, 2048}) {
     dmel_stft_plan* p = nullptr;
     CK(dmel_stft_plan_create(&p, nfft == 2048 ? 44100 : 24000, nfft, nfft, nfft / 4, nfft == 2048 ? 128 : 80, 0.0, 0.0, nullptr));
