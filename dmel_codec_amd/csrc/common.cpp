@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <map>
+#include <atomic>
 #include <mutex>
 
 namespace dmel {
@@ -25,7 +26,7 @@ struct ProfRec {
 };
 struct ProfState {
   std::mutex mu;
-  bool on = false;
+  std::atomic<bool> on{false};   // read by every ProfScope constructor without the lock
   std::vector<std::string> families;
   std::vector<ProfRec> recs;
 };
