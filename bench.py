@@ -335,6 +335,8 @@ def main() -> None:
                          "achieved": round(ach, 2), "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": round(ach / peak, 4), "traffic": committed_traffic(conv),
                          "mfma_flops_issued_per_algorithmic_flop": round(factor, 3),
+                         # the same rate against the ceiling of rounds 1 / early 2, when every convolution issued six products (2500 / 6)
+                         "frac_of_six_product_ceiling": round(ach / (PEAK_BF16_MFMA_TFLOPS / 6.0), 4),
                          "frac_of_fp32_mfma_peak": round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                          "launches_per_step": conv["launches"] // max(1, args.steps),
                          "avg_launch_us": round(1e3 * conv["ms"] / max(1, conv["launches"]), 2),

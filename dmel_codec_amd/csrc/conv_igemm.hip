@@ -100,14 +100,21 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
       for (int mi = 0; mi < MT; ++mi) {
         const int mtile = mrow0 + mi * 32;
         if (mtile >= a.mtiles * 32) continue;
+        // RB rows at a time: all their residual / running-sum loads are issued before the first use, so the wave meets the HBM latency
+        // 16 / RB times per tile (4 -> 8 rows: the B fragments and, in the fp16-split kernel, the second accumulator set are dead here)
+#ifndef DMEL_EPI_ROWS
+#define DMEL_EPI_ROWS 8
+#endif
+        constexpr int RB = DMEL_EPI_ROWS;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {           // four rows at a time: all their loads are issued before the first use
-          float bias[4], rv[4][NT];
-          int co[4];
-          float ov[4][NT];          // previous output, for the running sum of the AMP branches (accumulate)
+        for (int g = 0; g < 16 / RB; ++g) {
+          float bias[RB], rv[RB][NT];
+          int co[RB];
+          float ov[RB][NT];          // previous output, for the running sum of the AMP branches (accumulate)
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            co[k] = mtile + k + 8 * g + 4 * h;
+          for (int k = 0; k < RB; ++k) {
+            const int r = g * RB + k;                                  // accumulator register -> row (r & 3) + 8 (r >> 2) + 4 h
+            co[k] = mtile + (r & 3) + 8 * (r >> 2) + 4 * h;
             const int cc = min(co[k], a.C - 1);
             bias[k] = a.bias[cc];
             if (rb) {
@@ -120,12 +127,12 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
             }
           }
 #pragma unroll
-          for (int k = 0; k < 4; ++k) {
+          for (int k = 0; k < RB; ++k) {
             if (co[k] >= a.C) continue;
             float* yrow = yb + co[k] * ycs + colbase;
 #pragma unroll
             for (int ni = 0; ni < NT; ++ni) {
-              float v = acc[mi][ni][4 * g + k] + bias[k];
+              float v = acc[mi][ni][g * RB + k] + bias[k];
               if (rb) v += rv[k][ni];
               if (a.accumulate) v += ov[k][ni];
               if (a.out_div != 1.f) v = v / a.out_div;
@@ -1068,11 +1075,12 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   if (d.mode == EPI_LINEAR) out_elems = (double)d.C * d.phases * (double)r.Tcols * (1.0 + (r.res ? 1.0 : 0.0) + (r.accumulate ? 1.0 : 0.0));
   else if (d.mode == EPI_GATE) out_elems = (double)d.C * (double)r.Tcols;
   else out_elems = (double)d.C * (double)r.Tcols * (r.skip_first ? 3.0 : 4.0);
-  const double alg_bytes = 4.0 * r.B * (in_elems + out_elems) + (double)pc.Mpad * pc.steps * kCK * 6.0;
+  double alg_bytes = 4.0 * r.B * (in_elems + out_elems);      // + the weight image read once, added below when the arithmetic is known
   static const int native_fp32 = [] { const char* e = getenv("DMEL_CONV_FP32_MFMA"); return e ? atoi(e) : 0; }();
   const bool one_piece = r.precision == DMEL_PRECISION_BF16 || train_precision_override() == DMEL_PRECISION_BF16;
   const bool native = !one_piece && (native_fp32 || r.precision == DMEL_PRECISION_FP32_MFMA);
   const double products = one_piece ? 1.0 : native ? 16.0 /* fp32 MFMA: 1/16 of the bf16 rate */ : r.precision == DMEL_PRECISION_FP32_F16X2 ? 3.0 : 6.0;
+  alg_bytes += (double)pc.Mpad * pc.steps * kCK * (one_piece ? 2.0 : native ? 4.0 : r.precision == DMEL_PRECISION_FP32_F16X2 ? 4.0 : 6.0);
   const double alg_flops = 2.0 * r.B * (double)r.Tcols * rows_real * pc.k_real;
   ProfScope ps("conv_igemm", stream, alg_flops, alg_bytes, alg_flops * products);
   if (r.precision == DMEL_PRECISION_BF16 || train_precision_override() == DMEL_PRECISION_BF16)
