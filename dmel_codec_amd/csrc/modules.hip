@@ -666,7 +666,10 @@ extern "C" int dmel_wavenet_forward_train(const dmel_wavenet* m, const float* x,
   const TrainPlan p = train_plan(m, N, T, workspace);
   DMEL_CHECK_ARG(workspace_bytes >= p.bytes, "wavenet_forward_train: workspace too small (%zu < %zu)", workspace_bytes, p.bytes);
   hipStream_t st = (hipStream_t)stream;
-  const int C = m->C, prec = train_precision(m);
+  // the forward of a CONDITIONED WaveNet (the decoder: nothing discrete downstream) runs on the three-product fp16 split like its inference
+  // forward; an unconditioned one (the encoder: its output is quantised) and every backward pass keep the six-product split
+  static const bool fwd_f16 = [] { const char* e = getenv("DMEL_TRAIN_FWD_F16X2"); return !(e && e[0] == '0'); }();
+  const int C = m->C, prec = (train_precision(m) == DMEL_PRECISION_FP32 && m->Ccond > 0 && fwd_f16) ? DMEL_PRECISION_FP32_F16X2 : train_precision(m);
   const size_t n = p.n;
   if (m->has_in) {  // wavenet.py:205-207
     ConvRun r = run_1seg(x, m->Cin, T, p.U, C, T, N);
