@@ -74,7 +74,7 @@ __device__ __forceinline__ bool in_gap(const KArgs& a, int q) {
 // ------------------------------------------------------------------ epilogue (shared by both kernels)
 // Lane (h, l31) holds, for each 32x32 tile, column l31 and rows (r&3) + 8*(r>>2) + 4*h, r = 0..15.
 // Row-only quantities (bias, row offsets, channel map) are computed once per row, outside the column loop.
-template <int MT, int NT, int MODE>
+template <int MT, int NT, int MODE, int RB = 4>      // RB: rows whose residual / running-sum loads are in flight together (lean LINEAR path)
 __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT][NT], int mrow0, int colbase, int b, int lb,
                                               int h) {
   const int tcols = (int)a.Tcols;
@@ -101,11 +101,8 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
         const int mtile = mrow0 + mi * 32;
         if (mtile >= a.mtiles * 32) continue;
         // RB rows at a time: all their residual / running-sum loads are issued before the first use, so the wave meets the HBM latency
-        // 16 / RB times per tile (4 -> 8 rows: the B fragments and, in the fp16-split kernel, the second accumulator set are dead here)
-#ifndef DMEL_EPI_ROWS
-#define DMEL_EPI_ROWS 8
-#endif
-        constexpr int RB = DMEL_EPI_ROWS;
+        // 16 / RB times per tile.  The fp16-split kernel asks for 8 (its second accumulator set is dead here: -0.15 ms per bench step); for the
+        // others 8 rows cost 32 registers and a wave of occupancy (100 -> 132 VGPRs on the 128 x 96 tile), so they keep 4.
 #pragma unroll
         for (int g = 0; g < 16 / RB; ++g) {
           float bias[RB], rv[RB][NT];
@@ -881,7 +878,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
         for (int r = 0; r < 16; ++r) acc[mi][ni][r] = fmaf(acl[mi][ni][r], 1.f / kF16LoScale, acc[mi][ni][r]) * f16_out;
   }
   if ((DMEL_EXP & 8) && acc[0][0][0] != 12345.f) return;
-  conv_epilogue<MT, NT, MODE>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
+  conv_epilogue<MT, NT, MODE, NP == 2 ? 8 : 4>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
 }
 
 template <int WM, int WN, int MT, int NT, int MODE, int HALO, int NP, int KG>
