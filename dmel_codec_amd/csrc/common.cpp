@@ -70,6 +70,12 @@ using namespace dmel;
 
 extern "C" const char* dmel_last_error(void) { return g_err.c_str(); }
 namespace dmel {
+DevBuf* thread_scratch(int which) {
+  static thread_local std::map<std::pair<int, int>, DevBuf> bufs;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  return &bufs[{dev, which}];
+}
 int& train_precision_override() {
   static thread_local int v = -1;
   return v;

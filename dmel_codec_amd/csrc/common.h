@@ -113,6 +113,10 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
+// Library-owned scratch of the calling thread on the CURRENT device (a process normally drives one GPU; a thread that moves between devices
+// gets one buffer per device instead of a pointer into another GPU's memory).
+DevBuf* thread_scratch(int which);      // which: 0 absmax ring, 1 weight-gradient partial tiles, 2 folded discriminator weights
+
 // Per-family launch timing (bench.py's roofline leg): hipEvents on the launch stream.
 struct ProfScope {
   // issue_flops: matrix-core flops actually issued for `flops` algorithmic ones (x6 for the bf16 split, x3 for the fp16 split, ...)

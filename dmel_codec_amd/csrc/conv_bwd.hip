@@ -588,7 +588,7 @@ static bool wgrad_big_tile() {
 int launch_absmax(const float* v, int64_t n, hipStream_t st, const uint32_t** out) {
   // a ring of device words: launches of one thread are ordered on their stream; the ring keeps earlier launches' words alive while later
   // ones are queued
-  static thread_local DevBuf ring;
+  DevBuf& ring = *thread_scratch(0);
   static thread_local unsigned next = 0;
   constexpr unsigned kSlots = 1024;
   if (!ring.p) {
@@ -644,7 +644,7 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
     if (!attr_ok) { set_error("conv_wgrad: could not raise the dynamic LDS limit to %zu bytes", kWgF16gLds); return DMEL_EUNSUPPORTED; }
     // partial tiles of all workgroups: library-owned scratch, reused by every launch of this thread (launches and their reductions are
     // ordered on the stream; a second stream driven by the same thread would need its own buffer)
-    static thread_local DevBuf scratch;
+    DevBuf& scratch = *thread_scratch(1);
     const size_t need = (size_t)tn * tm * groups * slices * 3 * 4096 * sizeof(float);
     if (scratch.bytes < need) {
       DMEL_HIP(hipStreamSynchronize(st));

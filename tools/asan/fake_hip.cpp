@@ -19,6 +19,7 @@ hipError_t hipMemcpy2DAsync(void* d, size_t dp, const void* s, size_t sp, size_t
   return hipSuccess;
 }
 hipError_t hipGetLastError(void) { return hipSuccess; }
+hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 const char* hipGetErrorString(hipError_t) { return "fake HIP runtime"; }
 hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (hipStream_t)std::malloc(8); return hipSuccess; }
