@@ -193,21 +193,23 @@ __global__ __launch_bounds__(256) void dwconv_bwd_kernel(const float* __restrict
   float acc[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) acc[k] = 0.f;
-  for (int n = 0; n < N; ++n) {
+  // threads walk the flattened (item, frame) index: the quantiser's rows are 23-46 frames long, one item per pass would leave 80 % of the
+  // workgroup idle (4 launches x 354 us per training step before; per-thread partial sums, so the summation order differs from a loop over items)
+  const int64_t total = (int64_t)N * T;
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int n = (int)(i / T), t = (int)(i - (int64_t)n * T);
     const int64_t base = ((int64_t)n * C + c) * T;
-    for (int t = threadIdx.x; t < T; t += 256) {
-      const float g = dh0[base + t];
-      float d = dres ? dres[base + t] : 0.f;
+    const float g = dh0[base + t];
+    float d = dres ? dres[base + t] : 0.f;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int td = t - k + 3;                       // y[td] used x[td + k - 3] = x[t]
-        if (td >= 0 && td < T) d = fmaf(w[k], dh0[base + td], d);
-        const int tx = t + k - 3;
-        if (tx >= 0 && tx < T) acc[k] = fmaf(g, x[base + tx], acc[k]);
-      }
-      acc[7] += g;
-      dx[base + t] = d;
+    for (int k = 0; k < 7; ++k) {
+      const int td = t - k + 3;                       // y[td] used x[td + k - 3] = x[t]
+      if (td >= 0 && td < T) d = fmaf(w[k], dh0[base + td], d);
+      const int tx = t + k - 3;
+      if (tx >= 0 && tx < T) acc[k] = fmaf(g, x[base + tx], acc[k]);
     }
+    acc[7] += g;
+    dx[base + t] = d;
   }
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
