@@ -103,13 +103,13 @@ __global__ __launch_bounds__(256) void layerscale_bwd_kernel(const float* __rest
   const int c = blockIdx.x;
   const float g = gamma[c];
   float s = 0.f;
-  for (int n = 0; n < N; ++n) {
-    const int64_t base = ((int64_t)n * C + c) * T;
-    for (int t = threadIdx.x; t < T; t += 256) {
-      const float d = dy[base + t];
-      s = fmaf(d, v[base + t], s);
-      dv[base + t] = d * g;
-    }
+  const int64_t total = (int64_t)N * T;                 // flattened (item, frame) index: rows are 23-46 frames long
+  for (int64_t i = threadIdx.x; i < total; i += 256) {
+    const int n = (int)(i / T);
+    const int64_t e = ((int64_t)n * C + c) * T + (i - (int64_t)n * T);
+    const float d = dy[e];
+    s = fmaf(d, v[e], s);
+    dv[e] = d * g;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
