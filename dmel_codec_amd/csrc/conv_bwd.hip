@@ -703,10 +703,18 @@ __global__ __launch_bounds__(256) void conv_bgrad_kernel(const float* __restrict
   const int co = blockIdx.x;
   const int pieces = (T + kBgPiece - 1) / kBgPiece, total = B * pieces;
   float s = 0.f;
-  for (int i = blockIdx.y; i < total; i += gridDim.y) {
-    const int b = i / pieces, t0 = (i - b * pieces) * kBgPiece, t1 = min(T, t0 + kBgPiece);
-    const float* row = dy + ((int64_t)b * Cout + co) * T;
-    for (int t = t0 + threadIdx.x; t < t1; t += 256) s += row[t];
+  if (T < 256) {      // short rows (the 92-frame WaveNet GEMMs): threads walk the flattened (item, frame) index, or most of them would idle
+    const int64_t n = (int64_t)B * T;
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) {
+      const int b = (int)(i / T);
+      s += dy[((int64_t)b * Cout + co) * T + (i - (int64_t)b * T)];
+    }
+  } else {
+    for (int i = blockIdx.y; i < total; i += gridDim.y) {
+      const int b = i / pieces, t0 = (i - b * pieces) * kBgPiece, t1 = min(T, t0 + kBgPiece);
+      const float* row = dy + ((int64_t)b * Cout + co) * T;
+      for (int t = t0 + threadIdx.x; t < t1; t += 256) s += row[t];
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
