@@ -542,9 +542,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     const int grp = tap / 3, g = tap - 3 * grp;
     const int64_t tile_stride = (int64_t)groups * tm * tn * 3 * 4096;            // one K slice
     const float* p = partial + ((((int64_t)grp * tm + y) * tn + x) * 3 + g) * 4096 + wave * 1024 + r * 64 + lane;
-    float sum = 0.f;
-    for (int sl = 0; sl < slices; ++sl) sum += p[sl * tile_stride];
-    dw[((int64_t)co * Cin + ci) * taps_out + tap_out + tap] += sum;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // four loads in flight per thread: the slices are 10^5-10^6 floats apart
+    int sl = 0;
+    for (; sl + 4 <= slices; sl += 4) {
+      s0 += p[(int64_t)sl * tile_stride];
+      s1 += p[(int64_t)(sl + 1) * tile_stride];
+      s2 += p[(int64_t)(sl + 2) * tile_stride];
+      s3 += p[(int64_t)(sl + 3) * tile_stride];
+    }
+    for (; sl < slices; ++sl) s0 += p[(int64_t)sl * tile_stride];
+    dw[((int64_t)co * Cin + ci) * taps_out + tap_out + tap] += (s0 + s1) + (s2 + s3);
   }
 }
 
