@@ -311,7 +311,7 @@ def main() -> None:
             kernel = ("conv_bf16_kernel<NP=3> (fp32 via exact 3-way bf16 operand split: 6 x v_mfma_f32_32x32x16_bf16 per 32x32x16 "
                       "block, fp32 accumulate)")
         else:
-            kernel = ("conv_bf16_kernel<NP=2> on the decode side (fp32 via 2-way fp16 operand split, 2^-24 relative: 3 x "
+            kernel = ("conv_bf16_kernel<NP=2> on the decode side (fp32 via 2-way fp16 operand split, 22 significant bits per operand as in 3xTF32: 3 x "
                       "v_mfma_f32_32x32x16_f16 per 32x32x16 block, two fp32 accumulators) + <NP=3> / wavenet_fused_kernel on the "
                       "encode side (3-way bf16 split, 6 MFMAs per block: the ids are defined by it)")
         out = {

@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
         if constexpr (NP == 2) acl[mi][ni][r] = 0.f;
       }
   // NP = 2: gradients span too many binades for fp16 as they are: dy is staged x 2^(13 - e), e the exponent of the launch's max |dy|
-  // (absmax_kernel), so that the largest gradient lands in [2^13, 2^14) and everything within 2^-28 of it keeps 2^-24 relative precision;
+  // (absmax_kernel), so that the largest gradient lands in [2^13, 2^14) and everything within 2^-28 of it keeps 2^-22 relative precision;
   // x is staged x 2^-6 like the forward kernel.  The product of the two scales is undone on the accumulators.
   float dy_mul = 1.f, x_mul = 1.f, out_mul = 1.f;
   if constexpr (NP == 2) {

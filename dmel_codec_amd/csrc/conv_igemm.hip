@@ -543,10 +543,10 @@ template <int WM, int WN, int MT, int NT, int MODE> static int launch_t(const KA
 //           32-cycle bf16 MFMAs per 32x32x16 block replace eight 64-cycle fp32 MFMAs: 2.67x less matrix-core time for the
 //           same fp32-grade result (tests: same error against the fp64 oracle as the fp32 MFMA kernel).
 //   NP = 2  "fp16 split" (DMEL_PRECISION_FP32_F16X2; the vocoder's default): every fp32 operand as TWO fp16 pieces, a = a_hi + 2^-11 a_lo
-//           with a_hi = fp16(a) and a_lo = fp16((a - a_hi) * 2^11), both round-to-nearest: |a - (a_hi + 2^-11 a_lo)| <= 2^-24 |a|, the unit
+//           with a_hi = fp16(a) and a_lo = fp16((a - a_hi) * 2^11), both round-to-nearest: |a - (a_hi + 2^-11 a_lo)| <= 2^-22 |a| (22 significant bits; fp32 has 24), four times the unit
 //           roundoff of fp32.  THREE partial products per block (v_mfma_f32_32x32x16_f16): a_hi b_hi into `acc`, a_hi b_lo + a_lo b_hi
 //           into a second accumulator `acl` that is folded in once, acc + 2^-11 acl, before the epilogue; the dropped a_lo b_lo is
-//           below 2^-24 |ab|.  Same measured error against fp64 as NP = 3 and as an fp32 fma chain, half the matrix-core time of NP = 3.
+//           below 2^-22 |ab|.  Same measured error against fp64 as NP = 3 and as an fp32 fma chain, half the matrix-core time of NP = 3.
 //           The second piece is kept SCALED so that it stays a normal fp16 number wherever the first one is; activations are staged
 //           x 2^-6 and the weight image carries 2^6 (exact), which centres the fp16 range on audio-network magnitudes: |x| < 4.19e6,
 //           absolute error 2^-30 below |x| = 2^-8.  Not used for gradients (too many binades) nor for the encoder (ids are defined
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   // a K step of MFMAs later, so no s_waitcnt lands between the loads and the math.  Addresses are a scalar base (batch
   // item) plus one unsigned 32-bit byte offset per lane: row offsets advance by additions, clamped to the last channel.
   // NP = 2 over a gradient tensor: staged x 2^(13 - e), e = exponent of the tensor's max |value| (the largest gradient lands in [2^13, 2^14),
-  // everything within 2^-27 of it keeps 2^-24 relative precision), instead of the fixed 2^-6 of activations; undone on the accumulators
+  // everything within 2^-27 of it keeps 2^-22 relative precision), instead of the fixed 2^-6 of activations; undone on the accumulators
   float f16_in = kF16XScale, f16_out = 1.f;
   if (NP == 2 && a.seg[0].in_absmax) {
     const int e = min(max((int)(*a.seg[0].in_absmax >> 23) - 127, -100), 100);

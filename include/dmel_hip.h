@@ -39,9 +39,10 @@ extern "C" {
  *      fp32") -- both meet the same error bound against an fp64 evaluation and tests hold them to it.
  *  FP32_MFMA: force the native v_mfma_f32_32x32x2_f32 kernel (every product one exact fp32 fma).
  *  FP32_F16X2: fp32-grade products from a TWO-way fp16 split of both operands (a = a_hi + 2^-11 a_lo, a_hi = fp16(a) round to nearest,
- *      a_lo = fp16((a - a_hi) 2^11): 2^-24 relative, the unit roundoff of fp32 itself) and THREE partial products on the fp16 matrix
+ *      a_lo = fp16((a - a_hi) 2^11): 22 significant bits, |a - (a_hi + 2^-11 a_lo)| <= 2^-22 |a|, against the 24 of fp32) and THREE partial products on the fp16 matrix
  *      cores (a_hi b_hi into one fp32 accumulator, a_hi b_lo + a_lo b_hi into a second one that is folded in with 2^-11 at the end; the
- *      dropped a_lo b_lo is < 2^-24 |ab|): the "3xTF32" construction with fp16 pieces -- half the matrix-core time of the six-product
+ *      dropped a_lo b_lo is < 2^-22 |ab|): the "3xTF32" construction with fp16 pieces (same 22 bits), whose errors are random in sign and
+ *      vanish under the rounding of a K ~ 10^3 fp32 accumulation -- half the matrix-core time of the six-product
  *      bf16 split for the same error against an fp64 evaluation (tests hold both to the same bound).  Inputs are staged as x 2^-6 and
  *      the weight image carries 2^6, so the fp16 range covers |x| < 4.19e6 (larger magnitudes overflow to inf -- loudly) and values
  *      below 2^-8 keep an ABSOLUTE error of 2^-30: use it for activations, not for back-propagated gradients.  The vocoder handle
