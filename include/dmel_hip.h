@@ -47,7 +47,10 @@ extern "C" {
  *      the weight image carries 2^6, so the fp16 range covers |x| < 4.19e6 (larger magnitudes overflow to inf -- loudly) and values
  *      below 2^-8 keep an ABSOLUTE error of 2^-30: use it for activations, not for back-propagated gradients.  The vocoder handle
  *      selects it by default (DMEL_PRECISION_FP32 there means "fp32-grade, library's choice"); WaveNet handles keep the six-product
- *      split unless asked, because the encoder's token ids are defined by it; training entry points always use the six-product split.
+ *      split unless asked, because the encoder's token ids are defined by it.  Training entry points choose per launch: the six-product split wherever a gradient
+ *      tensor is an operand as it is, the fp16 split where the operand is an activation (discriminator / decoder forward) or a gradient
+ *      tensor the library first scales by its own maximum (the discriminator's backward-data and long-row weight gradients: a reduction on
+ *      the same stream finds max |dy|, the kernel stages dy x 2^(13 - exponent)).
  *  FP32_BF16X3: force the six-product bf16 split where FP32 would pick the fp16 one.
  *  BF16: opt-in throughput mode, the library-side equivalent of running the reference's codec under dtype: bfloat16
  *      (config/lm/lm_config.yaml:1,83; models/lm_lit_modules.py:52-55): weights and staged activations rounded to bf16
