@@ -16,6 +16,7 @@
 // Measured (rocprofv3 --pmc, round 1): ~120 vector instructions per output and VALU active ~100 % of the kernel, i.e.
 // the kernel is VALU-issue bound at 2.3-2.6 TB/s, not HBM bound; the two sin^2 per input sample are a third of it.
 #include "ops.h"
+#include "snake_dev.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -24,33 +25,6 @@
 namespace dmel {
 
 constexpr int kSnakeTile = 1024;
-
-struct Taps12 {
-  float f[12];
-};
-
-// sin^2(x) for the Snake term.  Reduce x to r = x - n*(pi/2), |r| <= pi/4 (three-term Cody-Waite, exact products for
-// |n| < 2^13), evaluate the odd degree-9 polynomial of sin(r) and use sin^2(x) = s^2 (n even) or 1 - s^2 (n odd): the
-// sign of sin never matters.  Measured against fp64 on 1e7 points, |x| up to 3e4: max abs error 1.2e-7, rms 2.2e-8 --
-// slightly better than squaring a correctly rounded sinf -- at a third of the instructions of the library path.
-__device__ __forceinline__ float sin_sq(float x) {
-  if (fabsf(x) > 8192.f) {
-    const float s = sinf(x);
-    return s * s;
-  }
-  const float n = rintf(x * 0.63661977236758134308f);
-  float r = fmaf(n, -1.5703125f, x);
-  r = fmaf(n, -4.837512969970703125e-4f, r);
-  r = fmaf(n, -7.54978995489188216e-8f, r);
-  const float r2 = r * r;
-  float p = 2.7557314e-06f;
-  p = fmaf(p, r2, -1.9841270e-04f);
-  p = fmaf(p, r2, 8.3333333e-03f);
-  p = fmaf(p, r2, -1.6666667e-01f);
-  const float s = fmaf(r * r2, p, r);
-  const float s2 = s * s;
-  return ((int)n & 1) ? 1.0f - s2 : s2;
-}
 
 // 32-bit indices, and tiles that do not touch a sequence edge (block-uniform test) skip every clamp and select.
 // (A v_pk_fma_f32 version of this kernel measured 0.6x: packed fp32 issues at half rate on gfx950.  Four consecutive samples

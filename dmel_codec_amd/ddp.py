@@ -8,12 +8,19 @@ flatten / copy-back passes.  The decoder WaveNet hands its buffer over block by 
 (dmel_wavenet_backward_hooked), so block k's all-reduce is in flight while blocks k-1 ... 0 are still being differentiated
 (one bucket per WaveNet block, reverse layer order).
 
+Robustness: outstanding training forwards are tracked by weak references to their autograd contexts, so a graph dropped
+without backward cannot block later exchanges; `finish()` raises if a module produced gradients that never left; `exchange()` is the
+try/finally form of arm / backward / finish; `broadcast_parameters()` makes rank 0's weights everyone's before the first step and
+`check_parameters_in_sync()` compares a checksum across ranks.  The RCCL transport (backend "nccl", ReduceOp.AVG) has NOT run on hardware
+yet: every multi-rank test uses gloo.
+
 Every rank issues the same collectives in the same order by construction: the order is the order in which the (static) module graph is
 walked backwards, never which `.grad` happens to be None on a rank.  torch.distributed's NCCL (= RCCL) process group runs a collective
 on its own stream after the work already enqueued on the current stream, and `Work.wait()` makes the current stream wait for it: that
 is the side stream + event pair of the design, provided by the backend.  Under gloo (CPU tests) the same calls run on host threads."""
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -42,7 +49,10 @@ class GradReducer:
         """Route the native gradient buffers of `modules` (and their NativeModule children) through this reducer for the next backward
         pass.  No-op for a single rank: the modules keep handing their gradients to autograd."""
         from .models.modules._native import NativeModule
-        self._armed = []
+        if self._armed or self._pending:
+            # a previous pass was abandoned between arm() and finish() (an exception in backward): disarm its modules and join its
+            # collectives before anything new is issued, so that the ranks' collective sequences cannot interleave
+            self.abort()
         if not self.active:
             return
         for m in modules:
@@ -51,9 +61,36 @@ class GradReducer:
             for sub in m.modules():
                 if isinstance(sub, NativeModule):
                     sub._grad_sink = self
+                    sub._grads_delivered = sub._grads_submitted = False
                     self._armed.append(sub)
         if self.record_events:
             self.events.append(("arm", len(self._armed)))
+
+    def abort(self) -> None:
+        """Disarm every module and wait for whatever was already issued, without touching gradients any further.  For error paths:
+        the collectives a rank has issued must still complete on every rank."""
+        for sub in self._armed:
+            sub._grad_sink = None
+        self._armed = []
+        pending, self._pending = self._pending, []
+        for work, _, _ in pending:
+            try:
+                work.wait()
+            except Exception:       # the process group may already be broken: nothing more to do for this message
+                pass
+
+    @contextlib.contextmanager
+    def exchange(self, modules: Iterable[torch.nn.Module], optimizer: Optional[torch.optim.Optimizer] = None):
+        """`with reducer.exchange([modules], optimizer): loss.backward()` = arm, backward, finish -- and, if backward raises, disarm and
+        join what was issued before the exception propagates (an armed module left behind would send the next step's gradients into
+        a reducer whose collective order no longer matches the other ranks')."""
+        self.arm(modules)
+        try:
+            yield self
+        except BaseException:
+            self.abort()
+            raise
+        self.finish(optimizer)
 
     def submit(self, flat: torch.Tensor) -> None:
         """All-reduce (average) a contiguous 1-D fp32 gradient region in place, asynchronously.  Called in backward order."""
@@ -75,11 +112,21 @@ class GradReducer:
         message; wait for every collective of this pass.  After this the current stream sees averaged gradients everywhere."""
         from .models.modules._native import NativeModule
         native_owned = set()
+        stuck = []
         for sub in self._armed:
             sub._grad_sink = None
             for p in sub.parameters(recurse=True):
                 native_owned.add(id(p))
+            # gradients were pointed at the module's flat buffer but the buffer never left: some OTHER training forward of this module is
+            # still waiting for a backward that did not run in this pass.  Silently skipping the exchange would let the ranks diverge.
+            if sub._grads_delivered and not sub._grads_submitted:
+                stuck.append(f"{type(sub).__name__} ({sub._pending_train} training forward(s) without backward)")
         self._armed = []
+        if stuck:
+            self.abort()
+            raise RuntimeError("GradReducer.finish: gradients of " + ", ".join(stuck) + " were produced but not exchanged: a grad-enabled "
+                               "forward of the module is still alive without its backward (run such calls under torch.no_grad(), or "
+                               "drop their outputs before backward)")
         if not self.active:
             return
         world = dist.get_world_size(self.group)
@@ -117,3 +164,51 @@ class GradReducer:
         if self.record_events:
             self.events.append(("finish", n))
         del NativeModule
+
+
+def _flat_state(module: torch.nn.Module):
+    return [t for t in list(module.parameters()) + list(module.buffers()) if t is not None and t.numel() > 0]
+
+
+@torch.no_grad()
+def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> int:
+    """Rank `src`'s parameters and buffers become every rank's (what Lightning's DDP wrapper does when it is constructed;
+    train_codec.py:49-55 relies on it): identical seeds are then a convenience, not the thing consistency rests on.  Floating tensors
+    travel in chunks of one flat message per dtype; returns the number of tensors sent."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    tensors = _flat_state(module)
+    by_kind: dict = {}
+    for t in tensors:
+        by_kind.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), ts in by_kind.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src=src, group=group)
+        off = 0
+        for t in ts:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view(t.shape))        # in place: versions move, native handles re-pack on next use
+            off += n
+    return len(tensors)
+
+
+@torch.no_grad()
+def check_parameters_in_sync(module: torch.nn.Module, group=None, what: str = "parameters") -> None:
+    """Raise if the ranks hold different parameters: every rank contributes (sum, sum of squares, count) of its floating tensors in
+    float64 and the MIN and MAX over ranks must agree exactly (bit-identical weights give bit-identical sums)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    tensors = [t for t in _flat_state(module) if t.is_floating_point()]
+    dev = tensors[0].device if tensors else torch.device("cpu")
+    s = torch.zeros(3, dtype=torch.float64, device=dev)
+    for t in tensors:
+        d = t.detach().double()
+        s[0] += d.sum()
+        s[1] += (d * d).sum()
+        s[2] += t.numel()
+    lo, hi = s.clone(), s.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError(f"data-parallel ranks hold different {what}: checksum min {lo.tolist()} != max {hi.tolist()} "
+                           "(gradient exchange skipped somewhere, or the ranks started from different weights)")

@@ -225,10 +225,11 @@ class VQGAN(nn.Module):
         # reference's reduction after every backward)
         last_micro_batch = (batch_idx + 1) % self.accumulate_grad == 0
         if last_micro_batch:
-            self.grad_reducer.arm([self.discriminator])
-        self.manual_backward(loss_d)
+            with self.grad_reducer.exchange([self.discriminator], optim_d):       # arm / backward / finish, disarmed on error
+                self.manual_backward(loss_d)
+        else:
+            self.manual_backward(loss_d)
         if last_micro_batch:
-            self.grad_reducer.finish(optim_d)
             self.clip_gradients(optim_d, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
             optim_d.step()
             optim_d.zero_grad()
@@ -244,10 +245,11 @@ class VQGAN(nn.Module):
         if last_micro_batch:
             # the discriminator is NOT armed here: like in the reference, this backward leaves gradients on its parameters that are
             # only consumed (and exchanged, as part of the sum) by the next discriminator step
-            self.grad_reducer.arm([self.encoder, self.quantizer, self.decoder])
-        self.manual_backward(loss)                                                                               # :315
+            with self.grad_reducer.exchange([self.encoder, self.quantizer, self.decoder], optim_g):
+                self.manual_backward(loss)                                                                       # :315
+        else:
+            self.manual_backward(loss)
         if last_micro_batch:
-            self.grad_reducer.finish(optim_g)
             self.clip_gradients(optim_g, gradient_clip_val=1000.0, gradient_clip_algorithm="norm")
             optim_g.step()
             optim_g.zero_grad()

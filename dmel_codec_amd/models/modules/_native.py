@@ -3,6 +3,7 @@ parameters change (load_state_dict, in-place edits) and freed with the module.""
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional
 
 import torch
@@ -30,7 +31,13 @@ class NativeModule(nn.Module):
         self._train_precision = 0
         self._generation = 0          # bumped whenever the native weight images change (rebuild or device-side re-pack)
         self._grad_sink = None        # armed by ddp.GradReducer for the duration of one backward pass
-        self._pending_train = 0       # training forwards whose backward has not run yet
+        # autograd contexts of training forwards whose backward has not run yet.  WEAK references: a graph that is dropped without a
+        # backward (a grad-enabled forward in a callback, a step that raised) leaves the set by itself instead of blocking every later
+        # gradient exchange of this module
+        self._train_calls = weakref.WeakSet()
+        self._backward_ctx = None     # the context whose backward is running (set by _check_train_call)
+        self._grads_delivered = False  # while armed: parameter gradients were pointed at the flat buffer ...
+        self._grads_submitted = False  # ... and the buffer went to the reducer (GradReducer.finish checks the pair)
 
     # -- handle life cycle ---------------------------------------------------------------------
     def _native_state(self) -> dict:
@@ -85,16 +92,23 @@ class NativeModule(nn.Module):
         return self._handle
 
     # -- training calls: shared bookkeeping of the autograd Functions ---------------------------
+    @property
+    def _pending_train(self) -> int:
+        """Training forwards of this module whose graph is still alive and whose backward has not run."""
+        return len(self._train_calls)
+
     def _begin_train_call(self, ctx) -> None:
         """Called by a training Function's forward after module.native(): remembers which weight images the saved activations
         belong to.  An optimiser step between this forward and its backward re-packs the images in place (same handle address), which
         torch autograd would report as an in-place modification; the generation counter makes the native backward report it too."""
         ctx.generation = self._generation
-        self._pending_train += 1
+        self._train_calls.add(ctx)
 
     def _check_train_call(self, ctx) -> None:
+        self._backward_ctx = ctx
         if self._generation != ctx.generation or self._handle is None:
-            self._pending_train = max(0, self._pending_train - 1)
+            self._train_calls.discard(ctx)
+            self._backward_ctx = None
             raise RuntimeError(f"{type(self).__name__}: parameters changed (optimiser step / load_state_dict / .to()) between a "
                                "training forward and its backward")
 
@@ -106,7 +120,9 @@ class NativeModule(nn.Module):
         reducer once the last outstanding backward of this module has run, and autograd receives None for the parameters -- the
         all-reduce works in place on the buffer the optimiser will read, no flatten / copy-back passes.  streamed=True: the C side
         already submitted every region of `flat` through the on_ready hook."""
-        self._pending_train = max(0, self._pending_train - 1)
+        if self._backward_ctx is not None:
+            self._train_calls.discard(self._backward_ctx)
+            self._backward_ctx = None
         views = [flat[o:o + n].view(p.shape) if need else None for (p, o, n), need in zip(slots, needs)]
         sink = self._grad_sink
         if sink is None:
@@ -117,8 +133,12 @@ class NativeModule(nn.Module):
             if p.grad is not None:
                 v.add_(p.grad)
             p.grad = v
-        if not streamed and self._pending_train == 0:
+        self._grads_delivered = True
+        if streamed:
+            self._grads_submitted = True
+        elif self._pending_train == 0:
             sink.submit(flat)
+            self._grads_submitted = True
         return [None] * len(views)
 
     def _can_stream_grads(self, params, needs) -> bool:

@@ -14,7 +14,9 @@ order, not in tensors.  Every op has a fake (meta) implementation for shape prop
 path fails loudly without the GPU library."""
 from __future__ import annotations
 
+import collections
 import ctypes as C
+import weakref
 from typing import Optional
 
 import torch
@@ -24,22 +26,68 @@ from . import _lib
 
 
 # ----------------------------------------------------------------------------------------------------- filters (host constants)
-_taps_cache: dict = {}
+class _TensorKeyedCache:
+    """Values derived from a tensor (packed-weight handles, host copies of filter taps), tied to the LIFETIME of that tensor.
+
+    An entry is found through id(tensor) and is valid only while its weak reference still points to the very same object at the same
+    `_version` (and, when a second tensor took part, while that one is the same object at the same version).  A data_ptr() key is not
+    enough: the caching allocator hands the address of a freed weight to the next tensor of that size, and a fresh tensor starts at
+    version 0 again.  When the tensor dies its entry is destroyed by a finaliser; beyond `capacity` the least recently used entry goes.
+    """
+
+    def __init__(self, capacity: int, destroy=None):
+        self.capacity, self.destroy = capacity, destroy
+        self.entries: "collections.OrderedDict" = collections.OrderedDict()
+
+    def _drop(self, key):
+        e = self.entries.pop(key, None)
+        if e is not None and self.destroy is not None:
+            self.destroy(e["value"])
+
+    def get(self, tensor: Tensor, extra, other: Optional[Tensor] = None, any_other: bool = False):
+        key = (id(tensor), extra)
+        e = self.entries.get(key)
+        if e is None:
+            return None
+        ok = e["ref"]() is tensor and e["version"] == tensor._version
+        if ok and not any_other:
+            o = e["other"]() if e["other"] is not None else None
+            ok = (o is other) and (other is None or e["other_version"] == other._version)
+        if not ok:
+            self._drop(key)
+            return None
+        self.entries.move_to_end(key)
+        return e["value"]
+
+    def put(self, tensor: Tensor, extra, value, other: Optional[Tensor] = None):
+        key = (id(tensor), extra)
+        self._drop(key)
+        while len(self.entries) >= self.capacity:
+            self._drop(next(iter(self.entries)))
+        self.entries[key] = dict(ref=weakref.ref(tensor), version=tensor._version, value=value,
+                                 other=weakref.ref(other) if other is not None else None,
+                                 other_version=other._version if other is not None else None)
+        weakref.finalize(tensor, self._expire, key, weakref.ref(tensor))
+
+    def _expire(self, key, ref):
+        e = self.entries.get(key)
+        if e is not None and e["ref"]() is None:       # still the dead tensor's entry (not a newer tensor that reuses the id)
+            self._drop(key)
+
+
+_taps_cache = _TensorKeyedCache(256)
 
 
 def _host_taps(f: Tensor) -> Tensor:
     """12 filter taps as a host fp32 tensor.  The kernel takes them as launch constants; a device buffer is copied to the host ONCE per
-    (storage, version) -- not per call (the filters are registered buffers that never change after load)."""
+    (tensor object, version) -- not per call (the filters are registered buffers that never change after load)."""
     if f.device.type == "cpu" and f.dtype == torch.float32 and f.is_contiguous():
         t = f.detach().reshape(-1)
     else:
-        key = (f.data_ptr(), f._version, str(f.device))
-        t = _taps_cache.get(key)
+        t = _taps_cache.get(f, None)
         if t is None:
-            if len(_taps_cache) > 256:
-                _taps_cache.clear()
             t = f.detach().to("cpu", torch.float32).contiguous().reshape(-1)
-            _taps_cache[key] = t
+            _taps_cache.put(f, None, t)
     if t.numel() != 12:
         raise NotImplementedError("the fused anti-alias kernel is built for 12-tap filters (the only setting BigVGAN uses)")
     return t
@@ -118,25 +166,21 @@ def _(input, up_filter, down_filter, alpha, beta):
 
 
 # ----------------------------------------------------------------------------------------------------- dilated conv1d
-_conv_cache: dict = {}
+_conv_cache = _TensorKeyedCache(64, destroy=lambda h: _lib.lib().dmel_conv_destroy(h))
 
 
-def _conv_handle(weight: Tensor, bias: Optional[Tensor], dilation: int) -> int:
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), dilation,
-           None if bias is None else (bias.data_ptr(), bias._version))
-    h = _conv_cache.get(key)
+def _conv_handle(weight: Tensor, bias: Optional[Tensor], dilation: int, for_backward: bool = False) -> int:
+    """Packed-weight handle of (weight, bias, dilation): one entry per weight tensor, shared by forward and backward (backward does not
+    read the bias, so it takes whatever handle the forward built), rebuilt when the weight or the bias is modified in place or replaced."""
+    h = _conv_cache.get(weight, dilation, bias, any_other=for_backward)
     if h is None:
-        if len(_conv_cache) >= 64:
-            for old in _conv_cache.values():
-                _lib.lib().dmel_conv_destroy(old)
-            _conv_cache.clear()
         Cout, Cin, k = weight.shape
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = bias.detach().to("cpu", torch.float32).contiguous() if bias is not None else None
         hv = C.c_void_p()
         _lib.check(_lib.lib().dmel_conv_create(C.byref(hv), w.data_ptr(), _lib.ptr(b), Cout, Cin, k, dilation), "conv_create")
         h = hv.value
-        _conv_cache[key] = h
+        _conv_cache.put(weight, dilation, h, bias)
     return h
 
 
@@ -170,7 +214,7 @@ def conv1d_dilated_backward(x: Tensor, dy: Tensor, weight: Tensor, dilation: int
     dw = torch.empty(weight.shape, dtype=torch.float32, device=x.device)
     db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device)
     with torch.cuda.device(x.device):
-        h = _conv_handle(weight, None, dilation)
+        h = _conv_handle(weight, None, dilation, for_backward=True)
         L = _lib.lib()
         _lib.check(L.dmel_conv_backward_data(h, dy.data_ptr(), dx.data_ptr(), B, T, _lib.stream_ptr()), "conv_backward_data")
         _lib.check(L.dmel_conv_backward_weight(h, x.data_ptr(), dy.data_ptr(), dw.data_ptr(), db.data_ptr(), B, T, _lib.stream_ptr()),
@@ -200,25 +244,19 @@ conv1d_dilated.register_autograd(_conv_backward, setup_context=_conv_setup)
 
 
 # ----------------------------------------------------------------------------------------------------- transposed conv / output conv
-_convt_cache: dict = {}
+_convt_cache = _TensorKeyedCache(32, destroy=lambda h: _lib.lib().dmel_conv_transpose1d_destroy(h))
 
 
 def _convt_handle(weight: Tensor, bias: Optional[Tensor], stride: int) -> int:
-    key = (weight.data_ptr(), weight._version, str(weight.device), tuple(weight.shape), stride,
-           None if bias is None else (bias.data_ptr(), bias._version))
-    h = _convt_cache.get(key)
+    h = _convt_cache.get(weight, stride, bias)
     if h is None:
-        if len(_convt_cache) >= 32:
-            for old in _convt_cache.values():
-                _lib.lib().dmel_conv_transpose1d_destroy(old)
-            _convt_cache.clear()
         Cin, Cout, k = weight.shape
         w = weight.detach().to("cpu", torch.float32).contiguous()
         b = bias.detach().to("cpu", torch.float32).contiguous() if bias is not None else None
         hv = C.c_void_p()
         _lib.check(_lib.lib().dmel_conv_transpose1d_create(C.byref(hv), w.data_ptr(), _lib.ptr(b), Cin, Cout, k, stride), "conv_transpose1d_create")
         h = hv.value
-        _convt_cache[key] = h
+        _convt_cache.put(weight, stride, h, bias)
     return h
 
 

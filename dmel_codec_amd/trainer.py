@@ -222,6 +222,9 @@ class Trainer:
     def validate(self, model, datamodule) -> dict:
         was_training = model.training
         model.eval()
+        if self.world_size > 1:
+            from .ddp import check_parameters_in_sync
+            check_parameters_in_sync(model, what=f"parameters at global step {self.global_step}")
         total, count = 0.0, 0
         for i, batch in enumerate(datamodule.val_dataloader()):
             if self.limit_val_batches is not None and i >= self.limit_val_batches:
@@ -256,6 +259,12 @@ class Trainer:
         hooks = [o.register_step_post_hook(count) for o in optimizers]
         if ckpt_path:
             self.load_checkpoint(ckpt_path)
+        if self.world_size > 1:
+            # what Lightning's DDP wrapper does at construction (train_codec.py:49-55): rank 0's weights are everyone's; equal seeds are
+            # then a convenience.  The checksum is repeated at every validation (a skipped gradient exchange shows up there).
+            from .ddp import broadcast_parameters, check_parameters_in_sync
+            broadcast_parameters(model)
+            check_parameters_in_sync(model)
         for cb in self.callbacks:
             cb.setup(self, model)
         t0, seen0 = time.perf_counter(), 0.0

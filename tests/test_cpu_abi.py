@@ -218,3 +218,39 @@ def test_precision_entry_points_reject_bad_arguments(L):
     assert L.dmel_conv_set_precision(None, 0) < 0 and b"PRECISION" in L.dmel_last_error()
     assert L.dmel_wavenet_set_precision(None, 1) < 0
     assert L.dmel_bigvgan_set_precision(None, 1) < 0
+
+
+def test_handle_cache_is_tied_to_the_tensor_not_to_its_address():
+    """torch_ops caches packed-weight handles per weight tensor.  The key must be the tensor OBJECT and its version, never data_ptr():
+    the allocator hands a freed weight's address to the next tensor of that shape, and a fresh tensor starts at version 0 again."""
+    import gc
+    from dmel_codec_amd.torch_ops import _TensorKeyedCache
+    destroyed = []
+    cache = _TensorKeyedCache(3, destroy=destroyed.append)
+    w, b = torch.zeros(4, 4, 3), torch.zeros(4)
+    assert cache.get(w, 1, b) is None
+    cache.put(w, 1, "h1", b)
+    assert cache.get(w, 1, b) == "h1"
+    assert cache.get(w, 2, b) is None                                   # another dilation: its own entry
+    assert cache.get(w, 1, None, any_other=True) == "h1"                # backward does not care which bias the handle was built with
+    assert cache.get(w, 1, torch.zeros(4)) is None and destroyed == ["h1"]    # a different bias object: stale, destroyed, rebuilt by the caller
+    cache.put(w, 1, "h2", b)
+    w.add_(1.0)                                                         # in-place update (an optimiser step): version moves
+    assert cache.get(w, 1, b) is None and destroyed == ["h1", "h2"]
+    cache.put(w, 1, "h3", b)
+    b.mul_(2.0)
+    assert cache.get(w, 1, b) is None and destroyed[-1] == "h3"
+    # the tensor dies: its handle is destroyed, and a NEW tensor (same shape, version 0, quite possibly the same address / id) misses
+    cache.put(w, 1, "h4", b)
+    del w
+    gc.collect()
+    assert destroyed[-1] == "h4" and len(cache.entries) == 0
+    w2 = torch.zeros(4, 4, 3)
+    assert cache.get(w2, 1, b) is None
+    # least recently used goes first, one at a time
+    ts = [torch.zeros(2) for _ in range(4)]
+    for i, t in enumerate(ts[:3]):
+        cache.put(t, 0, f"t{i}")
+    assert cache.get(ts[0], 0) == "t0"                                  # touch 0: 1 is now the oldest
+    cache.put(ts[3], 0, "t3")
+    assert destroyed[-1] == "t1" and cache.get(ts[0], 0) == "t0" and cache.get(ts[2], 0) == "t2" and cache.get(ts[3], 0) == "t3"

@@ -132,7 +132,78 @@ def _reducer_worker(rank: int, world: int, port: int, out):
         opt.zero_grad()
         m(x).backward()
         g3 = [float(p.grad[0]) for p in m.w]
-        out.put((rank, order1, g1, uniform1, extra_g, unused.grad is None, m.dead.grad is None, order2, g2, g3, m._pending_train))
+        # ---- robustness of the exchange
+        from dmel_codec_amd.ddp import broadcast_parameters, check_parameters_in_sync
+        robust = {}
+        # (a) a grad-enabled forward whose graph is dropped without backward (an encode() in a callback) must not block later exchanges
+        opt.zero_grad()
+        dropped = m(x)
+        del dropped
+        events.clear()
+        with red.exchange([m], opt):
+            m(x).backward()
+        robust["dropped_graph_issues"] = [e for e in events if e[0] == "issue"]
+        robust["dropped_graph_grad"] = float(m.w[0].grad[0])
+        # (b) a LIVE forward without backward: the module's gradients cannot leave -> finish() raises instead of letting the ranks diverge
+        opt.zero_grad()
+        alive = m(x)
+        red.arm([m])
+        m(x).backward()
+        try:
+            red.finish(opt)
+            robust["stuck_raises"] = False
+        except RuntimeError as e:
+            robust["stuck_raises"] = "not exchanged" in str(e)
+        robust["disarmed_after_stuck"] = m._grad_sink is None
+        del alive
+        # (c) an exception inside the backward of an exchange() block disarms the modules
+        opt.zero_grad()
+        try:
+            with red.exchange([m], opt):
+                raise ValueError("backward failed")
+        except ValueError:
+            pass
+        robust["disarmed_after_error"] = m._grad_sink is None and not red._armed and not red._pending
+        # (d) the RCCL branch (ReduceOp.AVG inside the collective, no scale pass afterwards), with a stub: gloo has no AVG, so the stub
+        #     checks that AVG was asked for and performs SUM / world in its place
+        import dmel_codec_amd.ddp as ddp_mod
+        real_all_reduce, real_backend = dist.all_reduce, dist.get_backend
+        asked = []
+
+        class _DoneWork:
+            def wait(self):
+                return True
+
+        def fake_all_reduce(t, op=dist.ReduceOp.SUM, group=None, async_op=False):
+            asked.append(op)
+            if op == dist.ReduceOp.AVG:
+                real_all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                t.div_(world)
+                return _DoneWork() if async_op else None
+            return real_all_reduce(t, op=op, group=group, async_op=async_op)
+
+        ddp_mod.dist.all_reduce, ddp_mod.dist.get_backend = fake_all_reduce, (lambda group=None: "nccl")
+        try:
+            opt.zero_grad()
+            with red.exchange([m], opt):
+                m(x).backward()
+        finally:
+            ddp_mod.dist.all_reduce, ddp_mod.dist.get_backend = real_all_reduce, real_backend
+        robust["avg_ops"] = sum(1 for o in asked if o == dist.ReduceOp.AVG)
+        robust["avg_grad"] = [float(p.grad[0]) for p in m.w]
+        # (e) rank 0's parameters become everyone's; a checksum mismatch is reported
+        with torch.no_grad():
+            for p in m.w:
+                p.fill_(float(rank) + 0.25)
+        try:
+            check_parameters_in_sync(m)
+            robust["mismatch_detected"] = False
+        except RuntimeError:
+            robust["mismatch_detected"] = True
+        robust["n_broadcast"] = broadcast_parameters(m)
+        check_parameters_in_sync(m)
+        robust["after_broadcast"] = [float(p[0]) for p in m.w]
+        out.put((rank, order1, g1, uniform1, extra_g, unused.grad is None, m.dead.grad is None, order2, g2, g3, m._pending_train, robust))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -153,7 +224,11 @@ def test_gradient_exchange_overlaps_backward_two_ranks():
         p.join(60)
         assert p.exitcode == 0
     L, n = 4, 1000
-    for rank, order1, g1, uniform1, extra_g, unused_none, dead_none, order2, g2, g3, pending in res:
+    for rank, order1, g1, uniform1, extra_g, unused_none, dead_none, order2, g2, g3, pending, robust in res:
+        assert robust["dropped_graph_issues"] == [("issue", n)] * L and robust["dropped_graph_grad"] == 1.5
+        assert robust["stuck_raises"] and robust["disarmed_after_stuck"] and robust["disarmed_after_error"]
+        assert robust["avg_ops"] == L and robust["avg_grad"] == [1.5 * (k + 1) for k in range(L)]
+        assert robust["mismatch_detected"] and robust["n_broadcast"] == L + 1 and robust["after_broadcast"] == [0.25] * L
         # pass 1: computed(3), issue, computed(2), issue, ... : block k is on the wire before block k-1 is differentiated
         assert order1[0] == ("arm", 1)
         body = order1[1:1 + 2 * L]

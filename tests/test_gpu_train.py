@@ -256,6 +256,34 @@ def test_torch_ops_are_registered_and_match_the_oracle(dev):
         assert ops.bigvgan_forward(0, torch.empty(2, 80, 10, device="cuda"), 256, torch.empty(8, dtype=torch.uint8, device="cuda")).shape == (2, 1, 2560)
 
 
+def test_conv_op_with_fresh_weights_of_the_same_shape_every_call(dev):
+    """the op's packed-weight cache used to be keyed on (data_ptr, _version, shape); the caching allocator re-issues the
+    address of a freed weight, so a loop over fresh random weights silently reused the OLD handle from its third iteration on."""
+    import torch.nn.functional as F
+    from conftest import rel_err
+    import dmel_codec_amd.torch_ops  # noqa: F401
+    ops = torch.ops.dmel_hip
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 16, 120, generator=g).to(dev)
+    for it in range(6):
+        w = (torch.randn(32, 16, 3, generator=g) / 7.0).to(dev)          # same shape, previous one freed: very likely the same address
+        b = (torch.randn(32, generator=g) * 0.1).to(dev)
+        y = ops.conv1d_dilated(x, w, b, 1)
+        assert rel_err(y, F.conv1d(x.double(), w.double(), b.double(), padding=1)) < 2e-6, it
+        del w, b
+    wt_shape = (16, 8, 4)
+    for it in range(4):
+        wt = (torch.randn(*wt_shape, generator=g) / 5.0).to(dev)
+        yt = ops.conv_transpose1d(x, wt, None, 2)
+        assert rel_err(yt, F.conv_transpose1d(x.double(), wt.double(), None, stride=2, padding=1)) < 2e-6, it
+        del wt
+    # in-place update of a live weight (an optimiser step) is seen too
+    w = (torch.randn(32, 16, 3, generator=g) / 7.0).to(dev)
+    y0 = ops.conv1d_dilated(x, w, None, 1)
+    w.mul_(2.0)
+    assert rel_err(ops.conv1d_dilated(x, w, None, 1), 2.0 * y0) < 1e-6
+
+
 def _lib_ws(h, N, T):
     from dmel_codec_amd import _lib
     return _lib.lib().dmel_wavenet_workspace_bytes(h, N, T)
