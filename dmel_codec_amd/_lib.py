@@ -136,6 +136,7 @@ PROTOTYPES = {
     "dmel_conv_backward_data": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_conv_backward_weight": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_conv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
+    "dmel_conv_snake_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_prof_enable": (C.c_int, [C.c_int]),
     "dmel_prof_reset": (C.c_int, []),
     "dmel_prof_read": (C.c_int, [C.c_char_p, i64p, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double)]),

@@ -2449,42 +2449,65 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
       float *xj = bufs[3 + 3 * j], *uj = bufs[4 + 3 * j], *vj = bufs[5 + 3 * j];
       const float* xin = xu;
       static const int stagger = [] { const char* e = getenv("DMEL_BIGVGAN_STAGGER"); return e ? atoi(e) : 1; }();
+      // DMEL_FUSE_SNAKE=0: the two-kernel form (activation, then convolution) -- the A/B switch and the reference the fused kernel is
+      // held bit-identical to.  Read per call so that a test can flip it inside one process.
+      const char* fuse_env = getenv("DMEL_FUSE_SNAKE");
+      const bool fuse = !(fuse_env && fuse_env[0] == '0');
       for (int l = 0; l < 3; ++l) {
         // stagger the branches by one kernel: started together they run snake|snake|snake then conv|conv|conv in lockstep
         // and the VALU-bound activations never meet the matrix-pipe-bound convolutions on a CU
         if (l == 0 && multi && stagger && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_stag[j - 1], 0));
         if (c.resblock_type == 2) {   // AMPBlock2.forward (bigvgan.py:232-237): xt = a(x); xt = c(xt); x = xt + x
-          DMEL_TRY(launch_aa_snake(xin, uj, ab.act[l].alpha.as<float>(), ab.act[l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
-          if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
           ConvRun r2 = run_1seg(uj, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
           r2.res = xin; r2.res_bs = bs; r2.res_cs = Tc;
+          r2.precision = prec;
+          const bool fuse2 = fuse && conv_snake_eligible(ab.c1[l], r2);
+          if (!fuse2) DMEL_TRY(launch_aa_snake(xin, uj, ab.act[l].alpha.as<float>(), ab.act[l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
+          if (!fuse2 && l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
           if (l == 2) {
             r2.accumulate = j > 0;
             if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
             if (multi && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
           }
-          r2.precision = prec;
-          DMEL_TRY(launch_conv(ab.c1[l], r2, sj));
+          if (fuse2) {
+            r2.seg[0].x = xin;
+            DMEL_TRY(launch_conv_snake(ab.c1[l], r2, ab.act[l].alpha.as<float>(), ab.act[l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, sj));
+            if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
+          } else {
+            DMEL_TRY(launch_conv(ab.c1[l], r2, sj));
+          }
           if (l == 2 && multi && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_chain[j], sj));
           xin = xj;
           continue;
         }
-        DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
-        if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
         ConvRun r1 = run_1seg(uj, ch, Tc, vj, ch, Tc, B);
         r1.precision = prec;
-    DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
-        DMEL_TRY(launch_aa_snake(vj, uj, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
+        if (fuse && conv_snake_eligible(ab.c1[l], r1)) {       // act -> conv as ONE kernel: the activated tensor never exists in HBM
+          r1.seg[0].x = xin;
+          DMEL_TRY(launch_conv_snake(ab.c1[l], r1, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, sj));
+          if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
+        } else {
+          DMEL_TRY(launch_aa_snake(xin, uj, ab.act[2 * l].alpha.as<float>(), ab.act[2 * l].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
+          if (l == 0 && multi && stagger && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_stag[j], sj));
+          DMEL_TRY(launch_conv(ab.c1[l], r1, sj));
+        }
         ConvRun r2 = run_1seg(uj, ch, Tc, l < 2 ? xj : xs, ch, Tc, B);
         r2.res = xin; r2.res_bs = bs; r2.res_cs = Tc;
+        r2.precision = prec;
+        const bool fuse2 = fuse && conv_snake_eligible(ab.c2[l], r2);
+        if (!fuse2) DMEL_TRY(launch_aa_snake(vj, uj, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps_up, m->taps_dn, logscale, B, ch, Tc, sj));
         if (l == 2) {
           // xs = ((out_0 + out_1) + out_2) / 3, in the reference's order: block j's last conv runs behind block j-1's
           r2.accumulate = j > 0;
           if (j == c.num_kernels - 1) r2.out_div = (float)c.num_kernels;
           if (multi && j > 0) DMEL_HIP(hipStreamWaitEvent(sj, m->ev_chain[j - 1], 0));
         }
-        r2.precision = prec;
-    DMEL_TRY(launch_conv(ab.c2[l], r2, sj));
+        if (fuse2) {
+          r2.seg[0].x = vj;
+          DMEL_TRY(launch_conv_snake(ab.c2[l], r2, ab.act[2 * l + 1].alpha.as<float>(), ab.act[2 * l + 1].beta.as<float>(), m->taps_up, m->taps_dn, logscale, sj));
+        } else {
+          DMEL_TRY(launch_conv(ab.c2[l], r2, sj));
+        }
         if (l == 2 && multi && j + 1 < c.num_kernels) DMEL_HIP(hipEventRecord(m->ev_chain[j], sj));
         xin = xj;
       }

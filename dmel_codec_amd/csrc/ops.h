@@ -54,6 +54,13 @@ int launch_aa_snake(const float* x, float* y, const float* alpha, const float* b
                     const float* down_taps_host, int logscale, int B, int C, int64_t T, hipStream_t s);
 
 
+// Anti-aliased Snake fused into the convolution that reads it (conv_snake.hip): y = conv(snake(x)) with ConvRun's LINEAR epilogue
+// (bias, residual, running sum, 1 / out_div); r.seg[0].x is the tensor BEFORE the activation.  Bit-identical to launch_aa_snake +
+// launch_conv at DMEL_PRECISION_FP32_F16X2.  conv_snake_eligible: plain "same" convolution, fp16-split precision, no masks / strides.
+bool conv_snake_eligible(const PackedConv& pc, const ConvRun& r);
+int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha, const float* beta, const float* up_taps_host,
+                      const float* down_taps_host, int logscale, hipStream_t stream);
+
 // ---- training path (train_ops.hip, conv_bwd.hip) --------------------------------------------------------------
 int launch_gate_fwd(const float* pre, float* z, int N, int C, int64_t T, hipStream_t s);
 int launch_gate_bwd(const float* dz, const float* pre, float* dpre, int N, int C, int64_t T, hipStream_t s);

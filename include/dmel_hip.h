@@ -345,6 +345,15 @@ int dmel_conv_create(dmel_conv** c, const float* w_host, const float* bias_host 
 void dmel_conv_destroy(dmel_conv* c);
 int dmel_conv_set_precision(dmel_conv* c, int precision);
 int dmel_conv_forward(const dmel_conv* c, const float* x, float* y, int B, int64_t T, void* stream);
+/* Activation1d fused into the convolution that reads it: y = conv1d(Activation1d(x)) + bias (+ residual), the act -> conv pair of
+ * AMPBlock1 / AMPBlock2.forward (bigvgan/bigvgan.py:132-141, :232-237; alias_free_activation/torch/act.py:25-30) as ONE kernel --
+ * producer waves compute the anti-aliased Snake of the staged x tile in LDS while consumer waves run the MFMA loop, so the activated
+ * tensor never exists in HBM.  x (B, Cin, T) is the tensor BEFORE the activation; alpha / beta (Cin; beta NULL = Snake), filters and
+ * logscale as in dmel_aa_snake_f32; residual (B, Cout, T) nullable.  Always computes in DMEL_PRECISION_FP32_F16X2 and is
+ * BIT-IDENTICAL to dmel_aa_snake_f32 followed by dmel_conv_forward at that precision.  (k - 1) * dilation <= 64. */
+int dmel_conv_snake_forward(const dmel_conv* c, const float* x, const float* residual /*nullable*/, float* y, const float* alpha,
+                            const float* beta /*nullable*/, const float* up_filter12_host, const float* down_filter12_host,
+                            int logscale, int B, int64_t T, void* stream);
 /* Backward of the same convolution -- what autograd runs for the reference (`loss.backward()`, codec_lit_modules.py:236,315 ->
  * ATen conv1d backward); first piece of the training path (SURVEY.md section 8(f) rank 1, C-ABI row `conv1d_dilated(+_bwd)`).
  *   backward_data:   dx (B, Cin, T)  = conv1d(dy, W transposed and tap-reversed)   -- the forward kernel on a second weight image

@@ -277,6 +277,83 @@ def test_quantizer_encode_decode(dev, levels, prebound):
     assert rel_err(zq, zq_ref) < TOL
 
 
+# ------------------------------------------------------------------------------------ activation fused into the convolution
+@pytest.mark.parametrize("C_,k,dil,T,B,kind", [
+    (32, 3, 1, 100, 2, "snakebeta"), (32, 11, 5, 1000, 2, "snakebeta"), (32, 7, 1, 384, 1, "snake"), (32, 7, 3, 385, 1, "snakebeta"),
+    (64, 7, 3, 257, 1, "snakebeta"), (64, 3, 5, 192, 2, "snake"), (64, 11, 1, 600, 1, "snakebeta"),
+    (128, 3, 5, 130, 2, "snakebeta"), (128, 11, 5, 96, 2, "snakebeta"), (128, 7, 1, 97, 1, "snake"), (128, 11, 3, 311, 1, "snakebeta"),
+    (256, 11, 1, 96, 1, "snakebeta"), (256, 3, 3, 200, 2, "snake"), (256, 7, 5, 95, 1, "snakebeta"),
+    (48, 7, 1, 64, 2, "snakebeta"), (96, 3, 1, 7, 1, "snakebeta"), (24, 11, 5, 1, 2, "snakebeta"), (200, 3, 1, 50, 1, "snake"),
+    (384, 3, 1, 120, 1, "snakebeta"), (16, 7, 5, 2, 1, "snakebeta"), (128, 3, 1, 13, 1, "snakebeta"),
+])
+def test_conv_with_fused_activation_is_bit_identical_to_the_two_kernel_path(dev, C_, k, dil, T, B, kind):
+    """dmel_conv_snake_forward (act -> conv of AMPBlock1/2.forward, bigvgan.py:132-141, as one kernel with producer / consumer waves)
+    against dmel_aa_snake_f32 + dmel_conv_forward at the same precision: torch.equal, with and without the residual; and against the
+    oracle (Activation1d restated + F.conv1d, float64) at the conv bar.  Shapes: every consumer layout (32 / 64 / 128 / 256 rows, ragged
+    channel counts, more rows than one workgroup holds), both halos, tiles that end inside a row, rows shorter than the filters."""
+    from dmel_codec_amd import _lib
+    torch.manual_seed(C_ * 131 + k * 7 + dil + T)
+    w = torch.randn(C_, C_, k) / math.sqrt(C_ * k)
+    b = torch.randn(C_) * 0.1
+    x = torch.randn(B, C_, T) * 1.5
+    res = torch.randn(B, C_, T)
+    alpha, beta = torch.randn(C_) * 0.5, torch.randn(C_) * 0.5
+    taps = ref_cpu.aa_filter12().view(-1).contiguous()
+    L = _lib.lib()
+    h = C.c_void_p()
+    _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), b.data_ptr(), C_, C_, k, dil))
+    _lib.check(L.dmel_conv_set_precision(h, 3))                     # DMEL_PRECISION_FP32_F16X2: what the fused kernel computes in
+    xd, rd, ad = x.to(dev), res.to(dev), alpha.to(dev)
+    bd = beta.to(dev) if kind == "snakebeta" else None
+    for logscale in (1, 0):
+        a_ = ad if logscale else ad.abs() + 0.5
+        b_ = None if bd is None else (bd if logscale else bd.abs() + 0.5)
+        u = torch.empty_like(xd)
+        _lib.check(L.dmel_aa_snake_f32(xd.data_ptr(), u.data_ptr(), a_.data_ptr(), _lib.ptr(b_), taps.data_ptr(), taps.data_ptr(), logscale,
+                                       B, C_, T, _lib.stream_ptr()))
+        y2 = torch.empty(B, C_, T, device=dev)
+        _lib.check(L.dmel_conv_forward(h, u.data_ptr(), y2.data_ptr(), B, T, _lib.stream_ptr()))
+        y1 = torch.full((B, C_, T), float("nan"), device=dev)
+        _lib.check(L.dmel_conv_snake_forward(h, xd.data_ptr(), None, y1.data_ptr(), a_.data_ptr(), _lib.ptr(b_), taps.data_ptr(),
+                                             taps.data_ptr(), logscale, B, T, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        nbad = int((y1 != y2).sum())
+        assert nbad == 0, f"fused != two kernels at {nbad} of {y1.numel()} outputs (max diff {float((y1 - y2).abs().max()):.3e}), logscale {logscale}"
+        y1r = torch.full((B, C_, T), float("nan"), device=dev)
+        _lib.check(L.dmel_conv_snake_forward(h, xd.data_ptr(), rd.data_ptr(), y1r.data_ptr(), a_.data_ptr(), _lib.ptr(b_), taps.data_ptr(),
+                                             taps.data_ptr(), logscale, B, T, _lib.stream_ptr()))
+        assert torch.equal(y1r, y2 + rd)
+        a_c = a_.cpu().double()
+        b_c = a_c if b_ is None else b_.cpu().double()
+        f64 = ref_cpu.aa_filter12().double()
+        ref = F.conv1d(ref_cpu.activation1d(x.double(), a_c, b_c, f64, f64, logscale=bool(logscale)), w.double(), b.double(),
+                       dilation=dil, padding=dil * (k - 1) // 2)
+        assert rel_err(y1, ref) < 2e-5
+    L.dmel_conv_destroy(h)
+
+
+def test_bigvgan_fused_and_two_kernel_paths_agree_bit_for_bit(dev, golden, monkeypatch):
+    """The whole vocoder with the activations fused into the convolutions (default) and with DMEL_FUSE_SNAKE=0 (activation kernel +
+    convolution kernel): same bits, one stream or three, AMPBlock1 and AMPBlock2."""
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    from dmel_codec_amd.models.modules.bigvgan.env import AttrDict
+    for name in ("bigvgan_tiny", "bigvgan_tiny_ampblock2"):
+        g = golden(name)
+        m = BigVGAN(AttrDict(dict(g.meta["h"])))
+        m.load_state_dict(g.sd)
+        m = m.to(dev)
+        mel = g.ins["mel"].to(dev)
+        monkeypatch.setenv("DMEL_FUSE_SNAKE", "1")
+        y_f = m(mel)
+        monkeypatch.setenv("DMEL_FUSE_SNAKE", "0")
+        y_u = m(mel)
+        assert torch.equal(y_f, y_u), (name, float((y_f - y_u).abs().max()))
+        m.set_streams(1)
+        monkeypatch.setenv("DMEL_FUSE_SNAKE", "1")
+        assert torch.equal(m(mel), y_f)
+        assert rel_err(y_f, g.outs["audio"]) < TOL
+
+
 # ------------------------------------------------------------------------------------ BigVGAN
 def test_bigvgan_golden(dev, golden):
     from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
