@@ -52,8 +52,12 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
       ue = fmaf(tu.f[2 * j + 1], xp[2 - j], ue);
       uo = fmaf(tu.f[2 * j], xp[3 - j], uo);
     }
-    float ve = fmaf(inv_b, sin_sq(ue * a), ue);
-    float vo = fmaf(inv_b, sin_sq(uo * a), uo);
+    // both evaluations of sin^2 behind ONE wave-uniform test of the large-argument case: as two calls of sin_sq each is a basic block of
+    // its own and the two 20-deep dependency chains run one after the other (snake_dev.h)
+    float uu[2] = {ue, uo};
+    const float aa[2] = {a, a}, bb[2] = {inv_b, inv_b};
+    snake_n(uu, aa, bb);
+    float ve = uu[0], vo = uu[1];
     if (EDGE) {
       if (m < 0) vo = ve;          // replicate pad of the 2x signal: v[0] on the left ...
       if (m > T - 1) ve = vo;      // ... v[2T-1] on the right
@@ -62,8 +66,9 @@ __device__ __forceinline__ void aa_snake_tile(const float* __restrict__ xr, floa
   }
   __syncthreads();
   for (int o = tid; o < len; o += 256) {
-    const float2 p0 = vs[o], p1 = vs[o + 1], p2 = vs[o + 2], p3 = vs[o + 3], p4 = vs[o + 4], p5 = vs[o + 5],
-                 p6 = vs[o + 6];
+    float2 pv[7];
+    lds_read7_b64(vs + o, pv);          // seven conflict-free ds_read_b64 (the compiler's six ds_read2_b32 were two-way conflicts each)
+    const float2 p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3], p4 = pv[4], p5 = pv[5], p6 = pv[6];
     float acc = td.f[0] * p0.y;
     acc = fmaf(td.f[1], p1.x, acc);
     acc = fmaf(td.f[2], p1.y, acc);

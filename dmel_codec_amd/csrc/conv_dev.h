@@ -56,7 +56,8 @@ __device__ __forceinline__ bool in_gap(const KArgs& a, int q) {
 // ------------------------------------------------------------------ epilogue (shared by both kernels)
 // Lane (h, l31) holds, for each 32x32 tile, column l31 and rows (r&3) + 8*(r>>2) + 4*h, r = 0..15.
 // Row-only quantities (bias, row offsets, channel map) are computed once per row, outside the column loop.
-template <int MT, int NT, int MODE, int RB = 4>      // RB: rows whose residual / running-sum loads are in flight together (lean LINEAR path)
+// LEAN_ONLY: the caller guarantees the lean LINEAR case (no activation, row scale, phases or output stride): the general loop is not compiled
+template <int MT, int NT, int MODE, int RB = 4, bool LEAN_ONLY = false>      // RB: rows whose residual / running-sum loads are in flight together (lean LINEAR path)
 __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT][NT], int mrow0, int colbase, int b, int lb,
                                               int h) {
   const int tcols = (int)a.Tcols;
@@ -67,7 +68,7 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
     const int ycs = (int)a.y_cs, rcs = (int)a.res_cs, tout = (int)a.Tout;
     // The common case (plain conv, optionally + residual: 5 of 6 vocoder convs, every WaveNet projection) gets a loop
     // with no per-element flag tests: the general loop below spends more time in uniform branches than in stores.
-    const bool lean = a.act == ACT_NONE && !a.row_scale && a.phases == 1 && a.out_tstride == 1 && a.phase_base == 0;
+    const bool lean = LEAN_ONLY || (a.act == ACT_NONE && !a.row_scale && a.phases == 1 && a.out_tstride == 1 && a.phase_base == 0);
     if (lean) {
       const int tlim = min(tcols, tout);
       bool colok[NT], live[NT];

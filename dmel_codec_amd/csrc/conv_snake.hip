@@ -37,7 +37,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 struct SnakeArgs {
   const float* alpha;
-  const float* beta;      // nullptr: Snake (beta = alpha)
+  const float* beta;      // Snake (beta = alpha): the alpha pointer again
   int logscale;
   Taps12 tu, td;          // up-sampling taps x 2, low-pass taps
 };
@@ -54,7 +54,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
   constexpr int PSZ = KG * XS;                            // uint4 per piece
   constexpr int NSEGMAX = (XS + kSegW - 1) / kSegW;
   constexpr int IPP = (8 * NSEGMAX + NPROD - 1) / NPROD;  // items (channel pair, column segment) per producer and chunk, at most
-  constexpr int SCR = 2 * kXRow + 4 * kXRow;              // floats of private LDS per producer: xs[2][kXRow], vs[2][kXRow] float2
+  constexpr int SCR = IPP * 2 * kXRow + 4 * kXRow;        // floats of private LDS per producer: xs[IPP][2][kXRow], vs[2][kXRow] float2
   extern __shared__ __attribute__((aligned(16))) float smem[];
   uint4* Xb = reinterpret_cast<uint4*>(smem);             // [2 buffers][2 pieces][KG][XS] x 16 bytes
 
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
     const int tile = min(mblk * WM + wave_m, a.mtiles - 1);
     const char* wT = reinterpret_cast<const char*>(a.w32h) + (size_t)tile * steps * 2048;
     const uint32_t lane16 = lane * 16;
-    auto load_w = [&](uint4 (&dst)[2], int step) {
+    auto load_w = [&](uint4 (&dst)[2], int step) __attribute__((always_inline)) {
       const char* sp = wT + (size_t)step * 2048;
       dst[0] = *reinterpret_cast<const uint4*>(sp + lane16);
       dst[1] = *reinterpret_cast<const uint4*>(sp + 1024 + lane16);
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
     __syncthreads();                                      // chunk 0 is staged
     int tap = 0, xbuf = 0;
     constexpr int kWaitW = (2 & 15) | (7 << 4) | (15 << 8);      // s_waitcnt vmcnt(2): the weights of the next step have landed
-    auto k_step = [&](auto R, int s) {
+    auto k_step = [&](auto R, int s) __attribute__((always_inline)) {
       constexpr int r = decltype(R)::value;
       uint4 (&use)[2] = wa[r % (PD + 1)];
       load_w(wa[(r + PD) % (PD + 1)], min(s + PD, steps - 1));   // unconditional: see conv_bf16_kernel (a branch here costs a vmcnt(0))
@@ -125,17 +125,19 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[0][ni][r] = fmaf(acl[ni][r], 1.f / kF16LoScale, acc[0][ni][r]);
-    conv_epilogue<1, NT, EPI_LINEAR, 8>(a, acc, (mblk * WM + wave_m) * 32, q0 + wave_n * (NT * 32) + l31, b, b, h);
+    conv_epilogue<1, NT, EPI_LINEAR, 8, true>(a, acc, (mblk * WM + wave_m) * 32, q0 + wave_n * (NT * 32) + l31, b, b, h);
     return;
   }
 
   // -------------------------------------------------------------------------------------------------- producer: the activation
+  // Work of a chunk: 8 channel pairs x nseg column segments of <= kSegW columns = "items"; producer p takes items p, p + NPROD, ...
+  // (at most IPP).  Per chunk: (1) the x rows of all its items, fetched into registers one chunk ahead, go to private LDS rows;
+  // (2) the loads of the next chunk are issued; (3) the items are computed one after the other (a run-time loop: one copy of the code).
   const int p = wave_u - NC;
-  float* xs0 = smem + 2 * 2 * PSZ * 4 + p * SCR;
-  float* xs1 = xs0 + kXRow;
-  float2* vs0 = reinterpret_cast<float2*>(xs0 + 2 * kXRow);
+  float* xsb = smem + 2 * 2 * PSZ * 4 + p * SCR;           // xs[IPP][2][kXRow]
+  float2* vs0 = reinterpret_cast<float2*>(xsb + IPP * 2 * kXRow);
   float2* vs1 = vs0 + kXRow;
-  for (int i = lane; i < SCR; i += 64) xs0[i] = 0.f;      // idle lanes read beyond what an item writes: keep that finite
+  for (int i = lane; i < SCR; i += 64) xsb[i] = 0.f;       // idle lanes read beyond what an item writes: keep that finite
   const int T = (int)a.seg[0].Tin, Cin = a.seg[0].Cin;
   const int wx = BN + (taps - 1) * dil;                   // staged columns: the tile plus the convolution's reach
   const int tau0 = q0 - a.seg[0].pad_left;                // input time of staged column 0
@@ -143,131 +145,158 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
   const float* xb = a.seg[0].x + (int64_t)b * a.seg[0].bstride;
   const int cs = (int)a.seg[0].cstride;
 
-  float pre[IPP][2][3];         // the row segments of the NEXT chunk, fetched while this one is computed
-  float pa[IPP][2], pib[IPP][2];
-  auto fetch = [&](auto R, int chunk) {
-    constexpr int r = decltype(R)::value;
-    const int it = p + NPROD * r;
-    if (it >= nitems) return;
-    const int cp = it & 7, sg = it >> 3;
-    const int j0 = sg * kSegW, w = min(kSegW, wx - j0);
-    const int tb = tau0 + j0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-      const int ch = min(chunk * 16 + 2 * cp + c, Cin - 1);
-      const float* xr = xb + (int64_t)ch * cs;
-#pragma unroll
-      for (int k = 0; k < 3; ++k) {
-        const int i = min(lane + 64 * k, w + 11);
-        pre[r][c][k] = xr[min(max(tb - 6 + i, 0), T - 1)];
-      }
-      float al = sa.alpha[ch], bt = sa.beta ? sa.beta[ch] : al;     // aa_snake_kernel's parameter forms, expression for expression
-      if (sa.logscale) {
-        bt = sa.beta ? expf(bt) : expf(al);
-        al = expf(al);
-      }
-      pa[r][c] = al;
-      pib[r][c] = 1.0f / (bt + 1e-9f);
+  float pre[IPP][2][3];
+  float raw_a, raw_b;           // the chunk's Snake parameters as stored: lane l holds channel 16 chunk + (l & 15)
+  auto fetch = [&](int chunk) __attribute__((always_inline)) {
+    {
+      const int ch = min(chunk * 16 + (lane & 15), Cin - 1);
+      raw_a = sa.alpha[ch];
+      raw_b = sa.beta[ch];            // Snake: the launcher passes alpha for beta (one more load beats a branch that waits for raw_a)
     }
-  };
-  auto produce = [&](auto R, int chunk, uint4* dst) {
-    constexpr int r = decltype(R)::value;
-    const int it = p + NPROD * r;
-    if (it >= nitems) return;
-    const int cp = it & 7, sg = it >> 3;
-    const int j0 = sg * kSegW, w = min(kSegW, wx - j0);
-    const int tb = tau0 + j0;
-    // x window -> private LDS (LDS operations of one wave execute in order: no barrier anywhere in an item)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      const int i = lane + 64 * k;
-      if (i < w + 12) { xs0[i] = pre[r][0][k]; xs1[i] = pre[r][1][k]; }
-    }
-    const float a0 = pa[r][0], a1 = pa[r][1], ib0 = pib[r][0], ib1 = pib[r][1];
-    const float sc0 = chunk * 16 + 2 * cp < Cin ? kF16XScale : 0.f, sc1 = chunk * 16 + 2 * cp + 1 < Cin ? kF16XScale : 0.f;
-    if (chunk + 1 < nchunk) fetch(R, chunk + 1);          // in flight while this item and the following ones are computed
-    const bool edge = tb - 6 < 0 || tb + w + 6 > T;       // wave-uniform
-    // pairs (v[2m], v[2m+1]) of the activated 2x signal, m = tb - 3 + pidx
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      if (ps * 64 >= w + 6) break;
-      const int pidx = ps * 64 + lane;
-      const int m = tb - 3 + pidx;
-      int idx = pidx + 3;                                 // xs index of x[m]
-      if (edge) idx = min(max(min(max(m, 0), T - 1) - tb + 6, 3), kXRow - 4);
-      const float* xp0 = xs0 + idx;
-      const float* xp1 = xs1 + idx;
-      float ue0 = 0.f, uo0 = 0.f, ue1 = 0.f, uo1 = 0.f;
-#pragma unroll
-      for (int j = 0; j < 6; ++j) {
-        ue0 = fmaf(sa.tu.f[2 * j + 1], xp0[2 - j], ue0);
-        uo0 = fmaf(sa.tu.f[2 * j], xp0[3 - j], uo0);
-        ue1 = fmaf(sa.tu.f[2 * j + 1], xp1[2 - j], ue1);
-        uo1 = fmaf(sa.tu.f[2 * j], xp1[3 - j], uo1);
-      }
-      float ve0 = fmaf(ib0, sin_sq(ue0 * a0), ue0), vo0 = fmaf(ib0, sin_sq(uo0 * a0), uo0);
-      float ve1 = fmaf(ib1, sin_sq(ue1 * a1), ue1), vo1 = fmaf(ib1, sin_sq(uo1 * a1), uo1);
-      if (edge) {
-        if (m < 0) { vo0 = ve0; vo1 = ve1; }              // replicate pad of the 2x signal: v[0] on the left ...
-        if (m > T - 1) { ve0 = vo0; ve1 = vo1; }          // ... v[2T-1] on the right
-      }
-      vs0[pidx] = make_float2(ve0, vo0);
-      vs1[pidx] = make_float2(ve1, vo1);
-    }
-    // outputs: column j0 + o, input time tb + o
-    uint32_t* d32 = reinterpret_cast<uint32_t*>(dst) + ((2 * cp) >> 3) * (XS * 4) + (((2 * cp) & 7) >> 1);
-#pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      if (ps * 64 >= w) break;
-      const int o = ps * 64 + lane;
-      float y[2];
+    for (int r = 0; r < IPP; ++r) {
+      const int it = p + NPROD * r;
+      if (it >= nitems) break;
+      const int cp = it & 7, sg = it >> 3;
+      const int j0 = sg * kSegW, w = min(kSegW, wx - j0);
+      const int tb = tau0 + j0;
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
-        const float2* vs = c ? vs1 : vs0;
-        const float2 p0 = vs[o], p1 = vs[o + 1], p2 = vs[o + 2], p3 = vs[o + 3], p4 = vs[o + 4], p5 = vs[o + 5], p6 = vs[o + 6];
-        float s = sa.td.f[0] * p0.y;
-        s = fmaf(sa.td.f[1], p1.x, s);
-        s = fmaf(sa.td.f[2], p1.y, s);
-        s = fmaf(sa.td.f[3], p2.x, s);
-        s = fmaf(sa.td.f[4], p2.y, s);
-        s = fmaf(sa.td.f[5], p3.x, s);
-        s = fmaf(sa.td.f[6], p3.y, s);
-        s = fmaf(sa.td.f[7], p4.x, s);
-        s = fmaf(sa.td.f[8], p4.y, s);
-        s = fmaf(sa.td.f[9], p5.x, s);
-        s = fmaf(sa.td.f[10], p5.y, s);
-        s = fmaf(sa.td.f[11], p6.x, s);
-        y[c] = s;
-      }
-      const int t = tb + o;
-      const bool ok = t >= 0 && t < T;                    // the convolution's zero padding
-      {
-        // the operand split of conv_bf16_kernel<NP = 2>::store_x: the scaled input is ROUNDED to fp32, then split (no contraction)
-#pragma clang fp contract(off)
-        const float v0 = (ok ? y[0] : 0.f) * sc0, v1 = (ok ? y[1] : 0.f) * sc1;
-        const f16x2 hi = __builtin_convertvector((f32x2){v0, v1}, f16x2);
-        const f16x2 lo = __builtin_convertvector((f32x2){(v0 - (float)hi[0]) * kF16LoScale, (v1 - (float)hi[1]) * kF16LoScale}, f16x2);
-        if (o < w) {
-          d32[(j0 + o) * 4] = __builtin_bit_cast(uint32_t, hi);
-          d32[PSZ * 4 + (j0 + o) * 4] = __builtin_bit_cast(uint32_t, lo);
-        }
+        const float* xr = xb + (int64_t)min(chunk * 16 + 2 * cp + c, Cin - 1) * cs;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) pre[r][c][k] = xr[min(max(tb - 6 + min(lane + 64 * k, w + 11), 0), T - 1)];
       }
     }
   };
-  auto for_items = [&](auto&& f) {
-    f(std::integral_constant<int, 0>{});
-    if constexpr (IPP > 1) f(std::integral_constant<int, 1>{});
-    if constexpr (IPP > 2) f(std::integral_constant<int, 2>{});
-    if constexpr (IPP > 3) f(std::integral_constant<int, 3>{});
-    static_assert(IPP <= 4, "at most four items per producer and chunk");
+  auto stage = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int r = 0; r < IPP; ++r) {
+      const int it = p + NPROD * r;
+      if (it >= nitems) break;
+      const int w = min(kSegW, wx - (it >> 3) * kSegW);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int i = lane + 64 * k;
+        if (i < w + 12) { xsb[(r * 2) * kXRow + i] = pre[r][0][k]; xsb[(r * 2 + 1) * kXRow + i] = pre[r][1][k]; }
+      }
+    }
   };
-  for_items([&](auto R) { fetch(R, 0); });
-  for_items([&](auto R) { produce(R, 0, Xb); });
-  __syncthreads();
-  for (int ck = 0; ck + 1 < nchunk; ++ck) {
-    uint4* dst = Xb + ((ck + 1) & 1) * (2 * PSZ);
-    for_items([&](auto R) { produce(R, ck + 1, dst); });
-    __syncthreads();
+  fetch(0);
+  for (int ck = 0; ck < nchunk; ++ck) {
+    uint4* dst = Xb + (ck & 1) * (2 * PSZ);
+    stage();                                              // LDS operations of one wave execute in order: no barrier anywhere in here
+    // the chunk's effective parameters, one channel per lane (aa_snake_kernel's forms, expression for expression); an item reads its
+    // two channels with v_readlane -- per-item loads of alpha / beta were four dependent memory round trips per item
+    float eff_a = raw_a, eff_b = raw_b;
+    if (sa.logscale) {
+      eff_b = expf(eff_b);        // Snake: raw_b is alpha, so this is expf(alpha) as in the activation kernel
+      eff_a = expf(eff_a);
+    }
+    const float eff_ib = 1.0f / (eff_b + 1e-9f);
+    if (ck + 1 < nchunk) fetch(ck + 1);                   // in flight while this chunk is computed
+#pragma unroll 1
+    for (int r = 0; r < IPP; ++r) {
+      const int it = p + NPROD * r;
+      if (it >= nitems) break;
+      const int cp = it & 7, sg = it >> 3;
+      const int j0 = sg * kSegW, w = min(kSegW, wx - j0);
+      const int tb = tau0 + j0;
+      const float* xs0 = xsb + (r * 2) * kXRow;
+      const float* xs1 = xs0 + kXRow;
+      float al[2], ib[2], sc[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        al[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eff_a), 2 * cp + c));
+        ib[c] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, eff_ib), 2 * cp + c));
+        sc[c] = ck * 16 + 2 * cp + c < Cin ? kF16XScale : 0.f;
+      }
+      const bool edge = tb - 6 < 0 || tb + w + 6 > T;     // wave-uniform
+      uint32_t* d32 = reinterpret_cast<uint32_t*>(dst) + ((2 * cp) >> 3) * (XS * 4) + (((2 * cp) & 7) >> 1);
+      // pairs (v[2m], v[2m+1]) of the activated 2x signal, m = tb - 3 + pidx: NPS passes of 64 lanes, two channels, even and odd
+      // sample -- 4 NPS independent dependency chains in ONE basic block
+      auto pairs = [&](auto NPS_) __attribute__((always_inline)) {
+        constexpr int NPS = decltype(NPS_)::value;
+        float u[4 * NPS], av[4 * NPS], bv[4 * NPS];
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int pidx = ps * 64 + lane;
+          const int m = tb - 3 + pidx;
+          int idx = pidx + 3;                             // xs index of x[m]
+          if (edge) idx = min(max(min(max(m, 0), T - 1) - tb + 6, 3), kXRow - 4);
+          const float* xp0 = xs0 + idx;
+          const float* xp1 = xs1 + idx;
+          float ue0 = 0.f, uo0 = 0.f, ue1 = 0.f, uo1 = 0.f;
+#pragma unroll
+          for (int j = 0; j < 6; ++j) {
+            ue0 = fmaf(sa.tu.f[2 * j + 1], xp0[2 - j], ue0);
+            uo0 = fmaf(sa.tu.f[2 * j], xp0[3 - j], uo0);
+            ue1 = fmaf(sa.tu.f[2 * j + 1], xp1[2 - j], ue1);
+            uo1 = fmaf(sa.tu.f[2 * j], xp1[3 - j], uo1);
+          }
+          u[4 * ps] = ue0; u[4 * ps + 1] = uo0; u[4 * ps + 2] = ue1; u[4 * ps + 3] = uo1;
+          av[4 * ps] = av[4 * ps + 1] = al[0]; av[4 * ps + 2] = av[4 * ps + 3] = al[1];
+          bv[4 * ps] = bv[4 * ps + 1] = ib[0]; bv[4 * ps + 2] = bv[4 * ps + 3] = ib[1];
+        }
+        snake_n(u, av, bv);
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int pidx = ps * 64 + lane;
+          const int m = tb - 3 + pidx;
+          float ve0 = u[4 * ps], vo0 = u[4 * ps + 1], ve1 = u[4 * ps + 2], vo1 = u[4 * ps + 3];
+          if (edge) {
+            if (m < 0) { vo0 = ve0; vo1 = ve1; }          // replicate pad of the 2x signal: v[0] on the left ...
+            if (m > T - 1) { ve0 = vo0; ve1 = vo1; }      // ... v[2T-1] on the right
+          }
+          vs0[pidx] = make_float2(ve0, vo0);
+          vs1[pidx] = make_float2(ve1, vo1);
+        }
+      };
+      // outputs: column j0 + o, input time tb + o
+      auto outs = [&](auto NPS_) __attribute__((always_inline)) {
+        constexpr int NPS = decltype(NPS_)::value;
+#pragma unroll
+        for (int ps = 0; ps < NPS; ++ps) {
+          const int o = ps * 64 + lane;
+          float y[2];
+#pragma unroll
+          for (int c = 0; c < 2; ++c) {
+            const float2* vs = c ? vs1 : vs0;
+            float2 pv[7];
+            lds_read7_b64(vs + o, pv);
+            const float2 p0 = pv[0], p1 = pv[1], p2 = pv[2], p3 = pv[3], p4 = pv[4], p5 = pv[5], p6 = pv[6];
+            float s = sa.td.f[0] * p0.y;
+            s = fmaf(sa.td.f[1], p1.x, s);
+            s = fmaf(sa.td.f[2], p1.y, s);
+            s = fmaf(sa.td.f[3], p2.x, s);
+            s = fmaf(sa.td.f[4], p2.y, s);
+            s = fmaf(sa.td.f[5], p3.x, s);
+            s = fmaf(sa.td.f[6], p3.y, s);
+            s = fmaf(sa.td.f[7], p4.x, s);
+            s = fmaf(sa.td.f[8], p4.y, s);
+            s = fmaf(sa.td.f[9], p5.x, s);
+            s = fmaf(sa.td.f[10], p5.y, s);
+            s = fmaf(sa.td.f[11], p6.x, s);
+            y[c] = s;
+          }
+          const int t = tb + o;
+          const bool ok = t >= 0 && t < T;                // the convolution's zero padding
+          {
+            // the operand split of conv_bf16_kernel<NP = 2>::store_x: the scaled input is ROUNDED to fp32, then split (no contraction)
+#pragma clang fp contract(off)
+            const float v0 = (ok ? y[0] : 0.f) * sc[0], v1 = (ok ? y[1] : 0.f) * sc[1];
+            const f16x2 hi = __builtin_convertvector((f32x2){v0, v1}, f16x2);
+            const f16x2 lo = __builtin_convertvector((f32x2){(v0 - (float)hi[0]) * kF16LoScale, (v1 - (float)hi[1]) * kF16LoScale}, f16x2);
+            if (o < w) {
+              d32[(j0 + o) * 4] = __builtin_bit_cast(uint32_t, hi);
+              d32[PSZ * 4 + (j0 + o) * 4] = __builtin_bit_cast(uint32_t, lo);
+            }
+          }
+        }
+      };
+      if (w + 6 > 64) pairs(std::integral_constant<int, 2>{}); else pairs(std::integral_constant<int, 1>{});
+      if (w > 64) outs(std::integral_constant<int, 2>{}); else outs(std::integral_constant<int, 1>{});
+    }
+    __syncthreads();                                      // chunk ck is staged (and chunk ck - 1 has been consumed)
   }
 }
 
@@ -275,7 +304,8 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
 template <int WM, int WN, int NT, int NPROD, int HALO>
 static int launch_cs(const KArgs& ka, const SnakeArgs& sa, int B, hipStream_t st) {
   constexpr int BN = WN * NT * 32, XS = BN + HALO;
-  constexpr size_t lds = (size_t)2 * 2 * 2 * XS * 16 + (size_t)NPROD * (6 * kXRow) * 4;
+  constexpr int IPP = (8 * ((XS + kSegW - 1) / kSegW) + NPROD - 1) / NPROD;
+  constexpr size_t lds = (size_t)2 * 2 * 2 * XS * 16 + (size_t)NPROD * ((IPP * 2 + 4) * kXRow) * 4;
   static_assert(lds <= 160 * 1024, "fused tile exceeds the LDS of a CU");
   auto kern = conv_snake_kernel<WM, WN, NT, NPROD, HALO>;
   if (lds > 64 * 1024) {
@@ -328,7 +358,7 @@ int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha
   DMEL_CHECK_ARG((int64_t)d.C * ka.y_cs < ((int64_t)1 << 31) && ka.Tout < ((int64_t)1 << 30), "conv_snake: one batch item of the output exceeds 32-bit offsets");
   ka.mtiles = pc.Mpad / 32;
   SnakeArgs sa;
-  sa.alpha = alpha; sa.beta = beta; sa.logscale = logscale;
+  sa.alpha = alpha; sa.beta = beta ? beta : alpha; sa.logscale = logscale;
   for (int i = 0; i < 12; ++i) { sa.tu.f[i] = 2.f * up_taps_host[i]; sa.td.f[i] = down_taps_host[i]; }
   const int halo = (sd.taps - 1) * sd.dil;
   const double in_elems = (double)sd.Cin * (double)r.seg[0].Tin;
@@ -342,7 +372,7 @@ int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha
   if (mt >= 5) return launch_cs_h<8, 1, 3, 4>(ka, sa, r.B, halo, stream);
   if (mt >= 3) return launch_cs_h<4, 1, 3, 8>(ka, sa, r.B, halo, stream);
   if (mt == 2) return launch_cs_h<2, 2, 3, 8>(ka, sa, r.B, halo, stream);
-  return launch_cs_h<1, 4, 3, 8>(ka, sa, r.B, halo, stream);
+  return launch_cs_h<1, 3, 3, 8>(ka, sa, r.B, halo, stream);      // 288 columns: three full segments for the eight producers
 }
 
 }  // namespace dmel

@@ -2449,10 +2449,12 @@ extern "C" int dmel_bigvgan_forward(const dmel_bigvgan* m, const float* mel, flo
       float *xj = bufs[3 + 3 * j], *uj = bufs[4 + 3 * j], *vj = bufs[5 + 3 * j];
       const float* xin = xu;
       static const int stagger = [] { const char* e = getenv("DMEL_BIGVGAN_STAGGER"); return e ? atoi(e) : 1; }();
-      // DMEL_FUSE_SNAKE=0: the two-kernel form (activation, then convolution) -- the A/B switch and the reference the fused kernel is
-      // held bit-identical to.  Read per call so that a test can flip it inside one process.
+      // DMEL_FUSE_SNAKE=1: every act -> conv pair as ONE kernel (conv_snake.hip: producer waves compute the activation, consumer waves run
+      // the MFMA loop).  Bit-identical to the two-kernel form and measured SLOWER on every vocoder shape (0.54-1.03x,
+      // profiles/r03_fused_vs_two_kernels.txt; DESIGN.md section 4 has the probes that explain it), so the two-kernel form stays the
+      // default.  Read per call so that a test can flip it inside one process.
       const char* fuse_env = getenv("DMEL_FUSE_SNAKE");
-      const bool fuse = !(fuse_env && fuse_env[0] == '0');
+      const bool fuse = fuse_env && fuse_env[0] == '1';
       for (int l = 0; l < 3; ++l) {
         // stagger the branches by one kernel: started together they run snake|snake|snake then conv|conv|conv in lockstep
         // and the VALU-bound activations never meet the matrix-pipe-bound convolutions on a CU

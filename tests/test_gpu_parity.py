@@ -333,8 +333,8 @@ def test_conv_with_fused_activation_is_bit_identical_to_the_two_kernel_path(dev,
 
 
 def test_bigvgan_fused_and_two_kernel_paths_agree_bit_for_bit(dev, golden, monkeypatch):
-    """The whole vocoder with the activations fused into the convolutions (default) and with DMEL_FUSE_SNAKE=0 (activation kernel +
-    convolution kernel): same bits, one stream or three, AMPBlock1 and AMPBlock2."""
+    """The whole vocoder with the activations fused into the convolutions (DMEL_FUSE_SNAKE=1) and as activation kernel + convolution
+    kernel (the default): same bits, one stream or three, AMPBlock1 and AMPBlock2."""
     from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
     from dmel_codec_amd.models.modules.bigvgan.env import AttrDict
     for name in ("bigvgan_tiny", "bigvgan_tiny_ampblock2"):
