@@ -136,6 +136,11 @@ PROTOTYPES = {
     "dmel_conv_backward_data": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_conv_backward_weight": (C.c_int, [vp, vp, vp, vp, vp, C.c_int, C.c_int64, vp]),
     "dmel_conv_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp]),
+    "dmel_stft_grad_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, vp]),
+    "dmel_stft_grad_destroy": (None, [vp]),
+    "dmel_stft_grad_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
+    "dmel_stft_magnitude_backward_f32": (C.c_int, [vp, vp, C.c_int64, vp, vp, C.c_int64, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
+    "dmel_collate_peak_f32": (C.c_int, [vp, vp, vp, vp, vp, vp, C.c_int, C.c_int64, C.c_float, vp]),
     "dmel_conv_snake_forward": (C.c_int, [vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int64, vp]),
     "dmel_prof_enable": (C.c_int, [C.c_int]),
     "dmel_prof_reset": (C.c_int, []),

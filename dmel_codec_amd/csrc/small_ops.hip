@@ -508,6 +508,66 @@ __global__ __launch_bounds__(256) void mask_add_quality_kernel(float* __restrict
   z[i] = v + (w[c] * value + bias[c]);
 }
 
+// ---- data front end: peak-normalise + right-pad collate      dataset/lhotse_tts_dataset.py:29-32 (librosa.util.normalize(audio) * 0.95),
+// :46-65 (right pad to the longest clip, stack to (B, 1, L), lengths (1, B) int32) ---------------------------------------------------------
+// Clips stay where the decoder / resampler left them (B separate device buffers): pass 1 reduces max |x| per clip (slices of a clip on the
+// grid, one atomic max on the bit pattern of a non-negative float per workgroup), pass 2 writes audios[b, 0, t] = x[t] / peak * 0.95 for
+// t < len and 0 behind it, plus the lengths row.  librosa leaves a clip whose peak is below the smallest normal float unscaled.
+constexpr int kCollateTile = 4096;
+__global__ __launch_bounds__(256) void collate_absmax_kernel(const float* const* __restrict__ clips, const int64_t* __restrict__ lens,
+                                                              const int32_t* __restrict__ order, uint32_t* __restrict__ peaks) {
+  const int b = blockIdx.y;
+  const int src = order ? order[b] : b;
+  const int64_t n = lens[src];
+  const int64_t t0 = (int64_t)blockIdx.x * kCollateTile;
+  if (t0 >= n) return;
+  const float* x = clips[src];
+  float m = 0.f;
+  for (int64_t t = t0 + threadIdx.x; t < min(n, t0 + kCollateTile); t += 256) m = fmaxf(m, fabsf(x[t]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  __shared__ float red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicMax(peaks + b, __float_as_uint(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+__global__ __launch_bounds__(256) void collate_scale_pad_kernel(const float* const* __restrict__ clips, const int64_t* __restrict__ lens,
+                                                                 const int32_t* __restrict__ order, const uint32_t* __restrict__ peaks,
+                                                                 float* __restrict__ audios, int32_t* __restrict__ lengths, int64_t Lmax,
+                                                                 float peak) {
+  const int b = blockIdx.y;
+  const int src = order ? order[b] : b;
+  const int64_t n = min(lens[src], Lmax);
+  if (blockIdx.x == 0 && threadIdx.x == 0) lengths[b] = (int32_t)n;
+  const float* x = clips[src];
+  const float m = __uint_as_float(peaks[b]);
+  const float length = m < 1.17549435e-38f ? 1.0f : m;      // librosa.util.normalize: norms below `tiny` are replaced by 1 (fill = None)
+  float* y = audios + (int64_t)b * Lmax;
+  const int64_t t0 = (int64_t)blockIdx.x * kCollateTile;
+  for (int64_t t = t0 + threadIdx.x; t < min(Lmax, t0 + kCollateTile); t += 256) y[t] = t < n ? (x[t] / length) * peak : 0.f;
+}
+
+}  // namespace dmel
+
+extern "C" int dmel_collate_peak_f32(const float* const* clips_dev, const int64_t* lengths_dev, const int32_t* order_dev, float* audios,
+                                     int32_t* audio_lengths, uint32_t* peaks_scratch, int B, int64_t Lmax, float peak, void* stream) {
+  using namespace dmel;
+  DMEL_CHECK_ARG(clips_dev && lengths_dev && audios && audio_lengths && peaks_scratch, "collate_peak: NULL argument");
+  DMEL_CHECK_ARG(B > 0 && B <= 65535 && Lmax > 0 && Lmax < ((int64_t)1 << 40), "collate_peak: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  DMEL_HIP(hipMemsetAsync(peaks_scratch, 0, (size_t)B * sizeof(uint32_t), s));
+  const dim3 grid((unsigned)((Lmax + kCollateTile - 1) / kCollateTile), (unsigned)B);
+  {
+    ProfScope ps("small", s, 0.0, 12.0 * B * (double)Lmax);
+    hipLaunchKernelGGL(collate_absmax_kernel, grid, dim3(256), 0, s, clips_dev, lengths_dev, order_dev, peaks_scratch);
+    hipLaunchKernelGGL(collate_scale_pad_kernel, grid, dim3(256), 0, s, clips_dev, lengths_dev, order_dev, peaks_scratch, audios,
+                       audio_lengths, Lmax, peak);
+  }
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
+namespace dmel {
 }  // namespace dmel
 
 extern "C" int dmel_mask_add_quality_f32(float* z, const int64_t* lengths, const float* w, const float* bias, float value,

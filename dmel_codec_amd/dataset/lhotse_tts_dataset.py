@@ -16,8 +16,39 @@ def peak_normalize(audio: torch.Tensor, peak: float = 0.95) -> torch.Tensor:
     threshold (the dtype's `tiny`) are left unscaled (lhotse_tts_dataset.py:32)."""
     m = audio.abs().amax(dim=-1, keepdim=True)
     tiny = torch.finfo(audio.dtype).tiny
-    scale = torch.where(m > tiny, 1.0 / m.clamp(min=tiny), torch.ones_like(m))
-    return audio * scale * peak
+    length = torch.where(m < tiny, torch.ones_like(m), m)       # librosa: norms below the threshold become 1 (fill = None)
+    return (audio / length) * peak                               # a division, then the 0.95: librosa's own order of operations
+
+
+def collate_clips_gpu(clips: Sequence[torch.Tensor], texts: Sequence[str] | None = None, paths: Sequence[str] | None = None,
+                      peak: float = 0.95) -> dict:
+    """peak_normalize + collate_clips in two launches of one native entry point (dmel_collate_peak_f32): the decoded mono clips (1-D fp32
+    CUDA tensors, wherever the decoder / resampler left them -- no concatenation) become the batch `training_step` consumes
+    (lhotse_tts_dataset.py:29-32, :46-65): longest first, x / max|x| * 0.95, right-padded, `audios (B,1,L)` f32 + `audio_lengths (1,B)` i32
+    on the device.  Only the sort by length runs on the host (lengths are known there; :20)."""
+    from .. import _lib
+    if not clips:
+        raise ValueError("empty batch")
+    dev = clips[0].device
+    for c in clips:
+        _lib.require_cuda(c, "clip")
+        if c.ndim != 1 or c.dtype != torch.float32 or not c.is_contiguous() or c.device != dev:
+            raise ValueError("clips must be contiguous 1-D float32 tensors on one device")
+    n = [int(c.shape[0]) for c in clips]
+    order = sorted(range(len(clips)), key=lambda i: -n[i])
+    B, Lmax = len(clips), max(n)
+    meta = torch.tensor([c.data_ptr() for c in clips] + n, dtype=torch.int64).to(dev, non_blocking=True)
+    order_dev = torch.tensor(order, dtype=torch.int32).to(dev, non_blocking=True)
+    audios = torch.empty(B, 1, Lmax, dtype=torch.float32, device=dev)
+    lengths = torch.empty(1, B, dtype=torch.int32, device=dev)
+    peaks = torch.empty(B, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.lib().dmel_collate_peak_f32(meta.data_ptr(), meta[B:].data_ptr(), order_dev.data_ptr(), audios.data_ptr(),
+                                                    lengths.data_ptr(), peaks.data_ptr(), B, Lmax, float(peak), _lib.stream_ptr()),
+                   "collate_peak")
+    return {"text": [texts[i] for i in order] if texts is not None else [""] * B,
+            "audios": audios, "audio_lengths": lengths,
+            "audio_paths": [paths[i] for i in order] if paths is not None else [""] * B}
 
 
 def collate_clips(clips: Sequence[torch.Tensor], texts: Sequence[str] | None = None, paths: Sequence[str] | None = None) -> dict:

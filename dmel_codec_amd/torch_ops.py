@@ -6,6 +6,7 @@ is (`anti_alias_activation_cuda.forward`, alias_free_activation/cuda/anti_alias_
     torch.ops.dmel_hip.aa_snake(x, alpha, beta?, up_filter, down_filter, logscale)                    # + autograd (native backward)
     torch.ops.dmel_hip.conv1d_dilated(x, weight, bias?, dilation)                                    # + autograd (dgrad / wgrad kernels)
     torch.ops.dmel_hip.stft_logmel(audio, lengths?, sample_rate, n_fft, win_length, hop_length, n_mels, f_min, f_max)
+    torch.ops.dmel_hip.stft_magnitude(audio, n_fft, win_length, hop_length)                           # + autograd (DFT-as-GEMM backward)
     torch.ops.dmel_hip.wavenet_forward(handle, x, condition?, in_lengths?, out_lengths?, group_repeat, out_channels)
     torch.ops.dmel_hip.bigvgan_forward(handle, mel, total_upsampling)
 
@@ -374,6 +375,61 @@ def stft_magnitude(audio: Tensor, n_fft: int, win_length: int, hop_length: int) 
 @stft_magnitude.register_fake
 def _(audio, n_fft, win_length, hop_length):
     return audio.new_empty((audio.shape[0], audio.shape[1] // hop_length, n_fft // 2 + 1), dtype=torch.float32)
+
+
+_stft_grads: dict = {}
+
+
+def _stft_grad_handle(device, n_fft, win_length, hop_length) -> int:
+    key = (str(device), n_fft, win_length, hop_length)
+    h = _stft_grads.get(key)
+    if h is None:
+        hv = C.c_void_p()
+        window = torch.hann_window(win_length, dtype=torch.float32)           # utils/spectrogram.py:53
+        with torch.cuda.device(device):
+            _lib.check(_lib.lib().dmel_stft_grad_create(C.byref(hv), n_fft, win_length, hop_length, window.data_ptr()), "stft_grad_create")
+        h = hv.value
+        _stft_grads[key] = h
+    return h
+
+
+@torch.library.custom_op("dmel_hip::stft_magnitude_backward", mutates_args=(), device_types="cuda")
+def stft_magnitude_backward(audio: Tensor, grad: Tensor, n_fft: int, win_length: int, hop_length: int) -> Tensor:
+    """d loss / d audio from d loss / d |S| (B, L // hop, n_fft // 2 + 1): dmel_stft_magnitude_backward_f32 -- both DFTs as GEMMs on the
+    library's convolution kernel, overlap-add with the reflect padding folded back."""
+    _lib.require_cuda(audio, "audio")
+    y = audio.float()
+    if y.stride(-1) != 1:
+        y = y.contiguous()
+    g = grad.float().contiguous()
+    B, Ls = y.shape
+    L = _lib.lib()
+    dy = torch.empty(B, Ls, dtype=torch.float32, device=y.device)
+    with torch.cuda.device(y.device):
+        h = _stft_grad_handle(y.device, n_fft, win_length, hop_length)
+        ws = torch.empty(L.dmel_stft_grad_workspace_bytes(h, B, Ls), dtype=torch.uint8, device=y.device)
+        _lib.check(L.dmel_stft_magnitude_backward_f32(h, y.data_ptr(), y.stride(0), g.data_ptr(), dy.data_ptr(), dy.stride(0), B, Ls,
+                                                      ws.data_ptr(), ws.numel(), _lib.stream_ptr()), "stft_magnitude_backward")
+    return dy
+
+
+@stft_magnitude_backward.register_fake
+def _(audio, grad, n_fft, win_length, hop_length):
+    return audio.new_empty(audio.shape, dtype=torch.float32)
+
+
+def _stft_mag_setup(ctx, inputs, output):
+    audio, n_fft, win_length, hop_length = inputs
+    ctx.save_for_backward(audio)
+    ctx.cfg = (n_fft, win_length, hop_length)
+
+
+def _stft_mag_backward(ctx, g):
+    (audio,) = ctx.saved_tensors
+    return stft_magnitude_backward(audio, g, *ctx.cfg), None, None, None
+
+
+stft_magnitude.register_autograd(_stft_mag_backward, setup_context=_stft_mag_setup)
 
 
 # ----------------------------------------------------------------------------------------------------- module-level ops

@@ -6,8 +6,11 @@ averaged over the resolutions, with the reference's own STFT framing (utils/spec
 checked against a torch.stft restatement in oracle/ref_cpu.py.  The magnitudes come from the fused STFT kernel
 (torch.ops.dmel_hip.stft_magnitude, one launch per signal and resolution, mel stage skipped).
 
-Forward only: the vocoder that would sit between the trained networks and this loss is frozen and has no backward here (it is unused by
-the reference's training_step), so the loss serves as a validation / evaluation metric (e.g. on validation_step's audios)."""
+Differentiable with respect to `pred` (round 3): torch.ops.dmel_hip.stft_magnitude has a native backward (dmel_stft_magnitude_backward_f32:
+the windowed DFT and its transpose as GEMMs on the library's convolution kernel, overlap-add with the reflect padding folded back), so
+the loss can train whatever produces the waveform.  In the reference's own training_step nothing does: the vocoder between the trained
+networks and a waveform is frozen (codec_lit_modules.py:68-72), so there the loss remains a validation metric; it becomes a training
+loss the moment a waveform-producing module is trainable (vocoder fine-tuning, which this package does not build)."""
 from __future__ import annotations
 
 from typing import Sequence
@@ -25,15 +28,16 @@ class MultiResolutionSTFTLoss(nn.Module):
         assert len(fft_sizes) == len(hop_sizes) == len(win_lengths)
         self.resolutions = list(zip(fft_sizes, hop_sizes, win_lengths))
 
-    @torch.no_grad()
     def forward(self, pred: torch.Tensor, target: torch.Tensor):
-        """pred / target: (B, L) or (B, 1, L) on the GPU -> (spectral convergence, log-magnitude L1), each averaged over resolutions."""
+        """pred / target: (B, L) or (B, 1, L) on the GPU -> (spectral convergence, log-magnitude L1), each averaged over resolutions.
+        Gradients flow to `pred` (the target's magnitudes are constants)."""
         if pred.ndim == 3:
             pred, target = pred[:, 0], target[:, 0]
         sc_total, mag_total = 0.0, 0.0
         for n_fft, hop, win in self.resolutions:
             sp = torch.ops.dmel_hip.stft_magnitude(pred, n_fft, win, hop)
-            st = torch.ops.dmel_hip.stft_magnitude(target, n_fft, win, hop)
+            with torch.no_grad():
+                st = torch.ops.dmel_hip.stft_magnitude(target, n_fft, win, hop)
             sc_total = sc_total + torch.linalg.norm(st - sp) / torch.linalg.norm(st)
             mag_total = mag_total + (st.log() - sp.log()).abs().mean()
         n = len(self.resolutions)

@@ -97,6 +97,19 @@ int dmel_stft_logmel_f32(const dmel_stft_plan* plan, const float* audio, int64_t
 int dmel_stft_f32(const dmel_stft_plan* plan, const float* audio, int64_t audio_row_stride, const int64_t* lengths,
                   float* logmel_out /*nullable*/, float* linear_out /*nullable*/, int B, int64_t L, void* stream);
 
+/* Backward of the linear magnitudes of dmel_stft_f32 -- what turns the multi-resolution STFT loss BASELINE.json's north_star names into a
+ * LOSS (the reference has neither; its STFT framing is utils/spectrogram.py:58-76).  grad_linear (B, T, n_fft/2 + 1) = dL/d|S|, frame-major
+ * like linear_out; daudio (B, L) is overwritten with dL/daudio.  The handle holds the windowed DFT matrix and its transpose in MFMA tile
+ * order: both transforms run as GEMMs on the library's convolution kernel (split-fp32 arithmetic), followed by an overlap-add that folds
+ * the reflect padding back.  n_fft any multiple of 16 up to 4096 (the forward kernel: 512 / 1024 / 2048). */
+typedef struct dmel_stft_grad dmel_stft_grad;
+int dmel_stft_grad_create(dmel_stft_grad** out, int n_fft, int win_length, int hop_length, const float* window_host /*nullable: periodic hann*/);
+void dmel_stft_grad_destroy(dmel_stft_grad* h);
+size_t dmel_stft_grad_workspace_bytes(const dmel_stft_grad* h, int B, int64_t L);
+int dmel_stft_magnitude_backward_f32(const dmel_stft_grad* h, const float* audio, int64_t audio_row_stride, const float* grad_linear,
+                                     float* daudio, int64_t daudio_row_stride, int B, int64_t L, void* workspace, size_t workspace_bytes,
+                                     void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Sample-rate conversion in front of the STFT    replaces torchaudio.functional.resample as called by
  * LogMelSpectrogram.forward(x, sample_rate=...) (utils/spectrogram.py:122-123): polyphase windowed-sinc filter bank,
@@ -106,6 +119,17 @@ int dmel_stft_f32(const dmel_stft_plan* plan, const float* audio, int64_t audio_
  * ---------------------------------------------------------------------------------------------- */
 int dmel_resample_f32(const float* x, float* y, const float* filter_bank_dev, int B, int64_t L, int64_t Lout, int orig_freq,
                       int new_freq, int width, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Data front end on the GPU: what LhotseTTSDataset.__getitem__ + collate_fn do to the decoded clips of
+ * a batch (dataset/lhotse_tts_dataset.py:29-32, :46-65): every clip peak-normalised, `librosa.util.normalize(audio) * 0.95` =
+ * x / max|x| * peak (a clip whose peak is below the smallest normal float is left unscaled, as librosa does), right-padded with zeros
+ * to Lmax and stacked: audios (B, 1, Lmax) f32, audio_lengths (1, B) int32.  clips_dev: B device pointers (device array) to the mono
+ * clips where the decoder / resampler left them; lengths_dev: their sample counts (device, int64); order_dev (nullable, device int32):
+ * output row b takes clip order[b] (the reference sorts a batch longest-first on the host, :20); peaks_scratch: B words.
+ * ---------------------------------------------------------------------------------------------- */
+int dmel_collate_peak_f32(const float* const* clips_dev, const int64_t* lengths_dev, const int32_t* order_dev /*nullable*/, float* audios,
+                          int32_t* audio_lengths, uint32_t* peaks_scratch, int B, int64_t Lmax, float peak, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Anti-aliased Snake / SnakeBeta           replaces fwd_cuda (anti_alias_activation_cuda.cu:212-246) and the

@@ -368,3 +368,95 @@ def test_train_codec_under_torch_distributed_run_two_ranks(dev, tmp_path):
     assert ckpt["global_step"] == 8 and not any("vocoder" in k for k in ckpt["state_dict"])
     lines = [l for l in open(tmp_path / "tb" / "dmel_codec_20hz" / "metrics.jsonl")]
     assert any("val_loss" in l for l in lines)
+
+
+# ------------------------------------------------------------------------------------ data front end and MR-STFT loss
+def test_collate_peak_normalise_and_pad_on_the_gpu(dev):
+    """dataset.collate_clips_gpu (dmel_collate_peak_f32) against the host path it replaces -- peak_normalize + collate_clips, i.e.
+    `librosa.util.normalize(audio) * 0.95`, longest first, right pad, (B,1,L) f32 + (1,B) i32 (dataset/lhotse_tts_dataset.py:29-32,
+    :46-65): bit-identical, including a silent clip (librosa leaves it unscaled), a one-sample clip and clips longer than a tile."""
+    from dmel_codec_amd.dataset import collate_clips, collate_clips_gpu, peak_normalize
+    g = torch.Generator().manual_seed(5)
+    lens = [24000, 9001, 1, 4097, 16000, 4096, 12345]
+    clips = [torch.randn(n, generator=g) * (0.01 + i) for i, n in enumerate(lens)]
+    clips[4] = torch.zeros(16000)                                  # silence: peak below `tiny` -> left as is
+    clips[1][17] = -37.5                                           # the peak is a negative sample
+    ref = collate_clips([peak_normalize(c) for c in clips], texts=[str(i) for i in range(len(clips))])
+    out = collate_clips_gpu([c.to(dev) for c in clips], texts=[str(i) for i in range(len(clips))])
+    assert out["text"] == ref["text"]
+    assert out["audios"].shape == ref["audios"].shape == (7, 1, 24000) and out["audio_lengths"].shape == (1, 7)
+    assert out["audio_lengths"].dtype == torch.int32 and torch.equal(out["audio_lengths"].cpu(), ref["audio_lengths"])
+    assert torch.equal(out["audios"].cpu(), ref["audios"])
+    assert float(out["audios"].abs().amax()) == pytest.approx(0.95, abs=1e-7)
+
+
+@pytest.mark.parametrize("n_fft,hop,win,L,B", [(1024, 120, 600, 4800, 2), (2048, 240, 1200, 7200, 1), (512, 50, 240, 3000, 3),
+                                               (1024, 256, 1024, 2560, 2), (512, 128, 512, 700, 1)])
+def test_stft_magnitude_backward_matches_autograd(dev, n_fft, hop, win, L, B):
+    """torch.ops.dmel_hip.stft_magnitude is differentiable (dmel_stft_magnitude_backward_f32: windowed DFT and its transpose as GEMMs on
+    the convolution kernel + overlap-add with the reflect padding folded back): d loss / d audio against torch.autograd through the
+    torch.stft restatement of the forward (oracle, utils/spectrogram.py:58-76) in float64, for a weighted sum of magnitudes and of
+    log(magnitude + 0.3) -- edges (reflect fold) included.  (A bare log would hand near-empty bins a weight of 1 / |S|^2 on the fp32
+    rounding of re / im: ill-conditioned in ANY fp32 implementation; the loss test below handles that case by comparison with fp32 autograd.)"""
+    from oracle import ref_cpu
+    from conftest import rel_err
+    import dmel_codec_amd.torch_ops  # noqa: F401
+    g = torch.Generator().manual_seed(n_fft + hop + L)
+    y = torch.randn(B, L, generator=g) * 0.3
+    T, K = L // hop, n_fft // 2 + 1
+    wgt = torch.randn(B, T, K, generator=g)
+    y64 = y.double().requires_grad_()
+    m64 = ref_cpu.stft_magnitude(y64, n_fft, win, hop).transpose(1, 2)  # (B, K, T) -> (B, T, K), float64
+    assert m64.shape == (B, T, K)
+    ((m64 * wgt.double()).sum() + (m64 + 0.3).log().sum()).backward()
+    yd = y.to(dev).requires_grad_()
+    m = torch.ops.dmel_hip.stft_magnitude(yd, n_fft, win, hop)
+    assert rel_err(m, m64.detach()) < 1e-4
+    ((m * wgt.to(dev)).sum() + (m + 0.3).log().sum()).backward()
+    # d|S|/d(re, im) = (re, im) / |S| is a unit vector: in near-empty bins its direction hangs on the fp32 rounding of re / im, in any
+    # fp32 implementation.  The bar is therefore the float32 autograd result's own distance from float64 (as in assert_close_to_truth).
+    y32 = y.clone().requires_grad_()
+    m32 = ref_cpu.stft_magnitude(y32, n_fft, win, hop).transpose(1, 2)
+    ((m32 * wgt).sum() + (m32 + 0.3).log().sum()).backward()
+    e_gpu, e_ref = rel_err(yd.grad, y64.grad), rel_err(y32.grad, y64.grad)
+    from conftest import report
+    report(f"stft magnitude backward n_fft {n_fft} hop {hop}: gpu-vs-fp64 {e_gpu:.2e}, fp32-autograd-vs-fp64 {e_ref:.2e}")
+    assert e_gpu < max(2e-5, 3.0 * e_ref), (e_gpu, e_ref)
+
+
+def test_mrstft_loss_trains_a_waveform(dev):
+    """MultiResolutionSTFTLoss is a loss: its gradient with respect to the predicted waveform matches autograd through the oracle's
+    definition in float64, and a few gradient steps on the waveform itself reduce it."""
+    from oracle import ref_cpu
+    from conftest import rel_err
+    from dmel_codec_amd.utils.mrstft import MultiResolutionSTFTLoss
+    g = torch.Generator().manual_seed(21)
+    target = torch.randn(2, 6000, generator=g) * 0.2
+    pred = target + 0.05 * torch.randn(2, 6000, generator=g)
+    p64 = pred.double().requires_grad_()
+    sc64, lm64 = ref_cpu.mrstft_loss(p64, target.double())
+    (sc64 + lm64).backward()
+    loss = MultiResolutionSTFTLoss()
+    pd = pred.to(dev).requires_grad_()
+    sc, lm = loss(pd[:, None, :], target.to(dev)[:, None, :])
+    assert abs(float(sc) - float(sc64)) < 1e-4 * abs(float(sc64)) and abs(float(lm) - float(lm64)) < 1e-4 * abs(float(lm64))
+    (sc + lm).backward()
+    # log |S| weighs near-empty bins by 1 / |S|^2: the fp32 rounding of re / im there dominates the error of any fp32 evaluation, so the
+    # bar is the float32 oracle's own distance from the float64 one (the criterion of assert_close_to_truth)
+    p32 = pred.clone().requires_grad_()
+    sc32, lm32 = ref_cpu.mrstft_loss(p32, target)
+    (sc32 + lm32).backward()
+    e_gpu, e_ref = rel_err(pd.grad, p64.grad), rel_err(p32.grad, p64.grad)
+    from conftest import report
+    report(f"mrstft gradient: gpu-vs-fp64 {e_gpu:.2e}, fp32-autograd-vs-fp64 {e_ref:.2e}")
+    assert e_gpu < max(1e-4, 3.0 * e_ref), (e_gpu, e_ref)
+    w = pred.to(dev).clone().requires_grad_()
+    opt = torch.optim.Adam([w], lr=2e-3)
+    first = None
+    for _ in range(12):
+        opt.zero_grad()
+        a, b = loss(w, target.to(dev))
+        (a + b).backward()
+        opt.step()
+        first = first if first is not None else float(a + b)
+    assert float(a + b) < 0.8 * first
