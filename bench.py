@@ -6,9 +6,10 @@ Workload (BASELINE.json configs[1]): full codec inference at 24 kHz, 80 mel bins
 vocoder, batch 32 of 1 s clips per GPU, fp32.  A "step" is one encode() + decode(return_audios=True) over one
 batch already resident in HBM; weights are seeded random (the reference ships none), audio is synthetic.
 One process per GPU; utterances shard across ranks with no data-path collective (weak scaling).  Rank 0 prints
-ONE JSON line with the whole-job rate, the roofline of the dominant kernel (the fp32-MFMA implicit-GEMM conv,
-timed live with hipEvents on the launch stream) and, at N=1, the CPU baseline (the oracle restatement made of
-the ATen-CPU calls the reference itself makes) timed on the host cores in the same run.
+ONE JSON line with the whole-job rate, the roofline of the dominant kernel family (the implicit-GEMM convolutions:
+fp32-grade products from the three-product fp16 split on the decode side and the six-product bf16 split on the
+encode side, timed live with hipEvents on the launch stream) and, at N=1, the CPU baseline (the oracle restatement
+made of the ATen-CPU calls the reference itself makes) timed on the host cores in the same run.
 """
 from __future__ import annotations
 
@@ -87,7 +88,7 @@ def cpu_baseline(codec, workload: str, seconds_per_clip: float, budget_s: float)
     all_cores = torch.get_num_threads()
     one()                                    # warm-up (thread pools, oneDNN primitives)
     calib = {}
-    for th in sorted({8, 32, all_cores}):
+    for th in sorted({1, 8, 32, all_cores}):
         if th > all_cores:
             continue
         torch.set_num_threads(th)
@@ -105,11 +106,22 @@ def cpu_baseline(codec, workload: str, seconds_per_clip: float, budget_s: float)
         el = time.perf_counter() - t0
         if el >= budget_s or reps >= 20:
             break
+    # one pass of the bench's own batch size (32 clips) at the same thread count: the 2-clip sample under-feeds oneDNN's batch loop
+    nb = 32
+    audio_b, lens_b = synth_audio(nb, L, 98), torch.full((nb,), L)
+    tb = time.perf_counter()
+    with torch.no_grad():
+        ids_b, il_b = ref_cpu.vqgan_encode(sd, cfg, audio_b, lens_b)
+        ref_cpu.vqgan_decode(sd, cfg, ids_b, il_b, torch.randn(nb, n_lat, ids_b.shape[2] * 4), voc, h)
+    batch32 = nb * seconds_per_clip / (time.perf_counter() - tb)
     torch.set_num_threads(all_cores)
     return {"value": round(n * seconds_per_clip * reps / el, 3), "unit": "audio-sec/sec", "cores": cores, "kind": "port",
+            "one_thread_audio_sec_per_sec": round(n * seconds_per_clip / calib[1], 3),
+            "batch32_one_pass_audio_sec_per_sec": round(batch32, 3),
             "sample": f"{reps} x (encode+decode of {n} x {seconds_per_clip:g} s clips) through oracle/ref_cpu.py "
                       f"(torch.stft / F.conv1d / F.conv_transpose1d), {el:.1f} s of CPU work on {cores} threads "
-                      f"(fastest of a one-pass calibration over {sorted(calib)} threads; host has {all_cores})",
+                      f"(fastest of a one-pass calibration over {sorted(calib)} threads; host has {all_cores}); plus one pass of "
+                      f"{nb} clips on the same threads and the 1-thread figure of the calibration",
             "one_pass_audio_sec_per_sec_by_threads": {str(k): round(n * seconds_per_clip / v, 3) for k, v in calib.items()}}
 
 
@@ -124,10 +136,60 @@ def committed_traffic(conv=None):
         alg = d.get("algorithmic_bytes_per_launch")
         if conv is not None and conv.get("launches"):
             alg = round(conv["bytes"] / conv["launches"])        # counted live by the library for exactly these launches
+        now = kernel_source_hash()
         return {"bytes_per_launch": d["bytes_per_launch"], "algorithmic_bytes_per_launch": alg,
-                "ratio": round(d["bytes_per_launch"] / alg, 3) if alg else None, "source": d.get("source")}
+                "ratio": round(d["bytes_per_launch"] / alg, 3) if alg else None,
+                "measured_in": "committed profile (profiles/pmc_traffic.json), NOT this run: bench.py cannot read hardware counters",
+                "kernel_source_hash_of_profile": d.get("kernel_source_hash"), "kernel_source_hash_now": now,
+                "stale": d.get("kernel_source_hash") != now,      # true: the convolution kernels changed since the PMC passes were taken
+                "source": d.get("source")}
     except (OSError, KeyError, ValueError):
         return None
+
+
+def kernel_source_hash() -> str:
+    """sha256 (first 16 hex digits) over the convolution kernel sources: ties a PMC figure to the code it was measured on."""
+    import hashlib
+    hsh = hashlib.sha256()
+    for name in ("conv_igemm.hip", "conv_dev.h", "conv.h", "wavenet_fused.hip"):
+        try:
+            with open(os.path.join(ROOT, "dmel_codec_amd", "csrc", name), "rb") as f:
+                hsh.update(f.read())
+        except OSError:
+            pass
+    return hsh.hexdigest()[:16]
+
+
+def visible_gpu_count() -> int:
+    """Number of GPUs a child rank will see, WITHOUT any torch.cuda / HIP call in this process (the launcher parent must provably never
+    initialise the GPU before it starts children): KFD topology nodes with a non-zero gfx_target_version, cut down by the
+    *_VISIBLE_DEVICES variables the runtime honours."""
+    import glob
+    n = 0
+    for prop in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            with open(prop) as f:
+                for line in f:
+                    k, _, v = line.partition(" ")
+                    if k == "gfx_target_version" and int(v.strip() or 0) != 0:
+                        n += 1
+        except (OSError, ValueError):
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
+def per_rank_times(dist, elapsed: float, device):
+    """Every rank's own wall time of the timed region (a straggler shows up here, not only in the max)."""
+    if dist is None:
+        return [elapsed]
+    t = torch.zeros(dist.get_world_size(), device=device, dtype=torch.float64)
+    t[dist.get_rank()] = elapsed
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(x) for x in t.tolist()]
 
 
 def max_over_ranks(dist, elapsed: float, device) -> float:
@@ -146,12 +208,12 @@ def job_rate(world: int, batch: int, seconds: float, steps: int, elapsed: float)
 
 def spawn_ranks(n: int, argv, script: str | None = None, have: int | None = None) -> int:
     """`python bench.py --gpus N` outside torch.distributed.run: become the launcher.  The N ranks are CHILD processes started before
-    this process has touched the GPU (device_count() does not initialise HIP on this image; nothing here execs a process that has),
+    this process has touched the GPU (the devices are counted from the KFD topology in sysfs, not through torch.cuda; nothing here execs),
     one per device, wired with the same RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* variables torch.distributed.run sets.  Rank 0's
     stdout (the one JSON line) is forwarded; the exit code is non-zero if any rank fails."""
     import socket
     import subprocess
-    have = torch.cuda.device_count() if have is None else have
+    have = visible_gpu_count() if have is None else have
     if have < n:
         print(f"bench.py --gpus {n} needs {n} devices on this node, found {have}", file=sys.stderr)
         return 2
@@ -256,6 +318,7 @@ def main() -> None:
         ids, wav = step()
     sync_all()
     elapsed = time.perf_counter() - t0
+    rank_elapsed = per_rank_times(dist, elapsed, dev)
     elapsed = max_over_ranks(dist, elapsed, dev)
 
     # Distribution of the step time: `median_steps` further steps, each bracketed by its own pair of events on the launch stream
@@ -312,7 +375,8 @@ def main() -> None:
                       "block, fp32 accumulate)")
         else:
             kernel = ("conv_bf16_kernel<NP=2> on the decode side (fp32 via 2-way fp16 operand split, 22 significant bits per operand as in 3xTF32: 3 x "
-                      "v_mfma_f32_32x32x16_f16 per 32x32x16 block, two fp32 accumulators) + <NP=3> / wavenet_fused_kernel on the "
+                      "v_mfma_f32_32x32x16_f16 per 32x32x16 block, two fp32 accumulators; inputs staged x 2^-6 with a FIXED scale: domain "
+                      "|x| < 4.19e6, absolute error floor 2^-30 below |x| = 2^-8, include/dmel_hip.h) + <NP=3> / wavenet_fused_kernel on the "
                       "encode side (3-way bf16 split, 6 MFMAs per block: the ids are defined by it)")
         out = {
             "metric": "audio-sec/sec (encode+decode RTF) @24 kHz batch 32",
@@ -320,6 +384,7 @@ def main() -> None:
             "unit": "audio-sec/sec",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "ms_per_step_by_rank": [round(1e3 * e / args.steps, 3) for e in rank_elapsed],
             "ms_per_step_events": ({"n": len(per_step_ms), "median": round(per_step_ms[len(per_step_ms) // 2], 3),
                                     "p10": round(per_step_ms[len(per_step_ms) // 10], 3),
                                     "p90": round(per_step_ms[(9 * len(per_step_ms)) // 10], 3)} if per_step_ms else None),

@@ -17,6 +17,7 @@
 // from ATen only by summation order.
 #include "conv.h"
 #include "conv_dev.h"
+#include "ops.h"
 #include <type_traits>
 
 #include <cmath>
@@ -880,7 +881,32 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     return launch_bf16_any<1>(ka, d.mode, r.B, r.Tcols, stream);
   // fp32: the split kernel is the default everywhere (after the wait-placement fixes it also wins on the 32-row, K < 128
   // layers of the last vocoder stage: 58 vs 72 us); the native fp32-MFMA kernels serve DMEL_PRECISION_FP32_MFMA
-  if (r.precision == DMEL_PRECISION_FP32_F16X2 && !native_fp32) return launch_bf16_any<2>(ka, d.mode, r.B, r.Tcols, stream);
+  if (r.precision == DMEL_PRECISION_FP32_F16X2 && !native_fp32) {
+    // Debug range check of the fp16 split's documented domain (include/dmel_hip.h: activations are staged x 2^-6, so |x| must stay below
+    // 2^6 * 65504 = 4.19e6; beyond that the first piece overflows to inf).  DMEL_DEBUG_F16_RANGE=1: reduce max |x| of every contiguous
+    // input of such a launch, synchronise, and fail the launch LOUDLY if it is outside the domain.  Off by default (it serialises).
+    static const int range_check = [] { const char* e = getenv("DMEL_DEBUG_F16_RANGE"); return e ? atoi(e) : 0; }();
+    if (range_check) {
+      for (int s = 0; s < d.nseg; ++s) {
+        const SegRun& sr = r.seg[s];
+        if (sr.in_absmax || sr.cstride != sr.Tin || sr.bstride != (int64_t)d.seg[s].Cin * sr.cstride) continue;     // scaled by its own maximum / a view
+        const uint32_t* slot = nullptr;
+        DMEL_TRY(launch_absmax(sr.x, (int64_t)r.B * sr.bstride, stream, &slot));
+        uint32_t bits = 0;
+        DMEL_HIP(hipMemcpyAsync(&bits, slot, sizeof(bits), hipMemcpyDeviceToHost, stream));
+        DMEL_HIP(hipStreamSynchronize(stream));
+        float mx;
+        std::memcpy(&mx, &bits, sizeof(mx));
+        if (!(mx * sr.in_scale < kF16WScale * 65504.f)) {
+          set_error("conv (fp16 split): max |x| = %g of input segment %d is outside the documented domain |x| < %g "
+                    "(DMEL_PRECISION_FP32_F16X2; use DMEL_PRECISION_FP32_BF16X3 for such tensors)", (double)mx * sr.in_scale, s,
+                    (double)(kF16WScale * 65504.f));
+          return DMEL_EINVAL;
+        }
+      }
+    }
+    return launch_bf16_any<2>(ka, d.mode, r.B, r.Tcols, stream);
+  }
   if ((r.precision == DMEL_PRECISION_FP32 || r.precision == DMEL_PRECISION_FP32_BF16X3 || r.precision == DMEL_PRECISION_FP32_F16X2) && !native_fp32)
     return launch_bf16_any<3>(ka, d.mode, r.B, r.Tcols, stream);
   const int tile = pick_tile(ka.mtiles, r.Tcols, r.B);

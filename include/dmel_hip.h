@@ -45,7 +45,12 @@ extern "C" {
  *      vanish under the rounding of a K ~ 10^3 fp32 accumulation -- half the matrix-core time of the six-product
  *      bf16 split for the same error against an fp64 evaluation (tests hold both to the same bound).  Inputs are staged as x 2^-6 and
  *      the weight image carries 2^6, so the fp16 range covers |x| < 4.19e6 (larger magnitudes overflow to inf -- loudly) and values
- *      below 2^-8 keep an ABSOLUTE error of 2^-30: use it for activations, not for back-propagated gradients.  The vocoder handle
+ *      below 2^-8 keep an ABSOLUTE error of 2^-30: use it for activations, not for back-propagated gradients.
+ *      DOMAIN, stated once more because inference launches do not rescale their inputs (training launches over gradients do):
+ *          |x| < 4.19e6 (= 2^6 * 65504), relative error 2^-22 for |x| >= 2^-8 = 3.9e-3, absolute error <= 2^-30 = 9.3e-10 below that
+ *          (0.5 % of a 1e-7 input, 7e-5 of a 1e-5 one: tests/test_gpu_parity.py::test_f16_split_conv_over_the_magnitude_range).
+ *      Audio-network activations (|x| ~ 1e-3 .. 1e2) sit inside it.  DMEL_DEBUG_F16_RANGE=1 makes every such launch reduce max |x| of
+ *      its input, synchronise and FAIL if the bound is exceeded (a debugging aid: it serialises the stream).  The vocoder handle
  *      selects it by default (DMEL_PRECISION_FP32 there means "fp32-grade, library's choice"); WaveNet handles keep the six-product
  *      split unless asked, because the encoder's token ids are defined by it.  Training entry points choose per launch: the six-product split wherever a gradient
  *      tensor is an operand as it is, the fp16 split where the operand is an activation (discriminator / decoder forward) or a gradient

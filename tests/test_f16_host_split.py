@@ -29,7 +29,7 @@ int main(int argc, char** argv) {
 
 
 @pytest.mark.skipif(shutil.which("g++") is None or not os.path.isdir("/opt/rocm/include"), reason="needs g++ and the HIP headers")
-def test_host_fp16_split_matches_ieee_and_carries_24_bits(tmp_path):
+def test_host_fp16_split_matches_ieee_and_carries_22_bits(tmp_path):
     rng = np.random.default_rng(3)
     bits = rng.integers(0, 2 ** 32, size=400000, dtype=np.uint64).astype(np.uint32)
     wide = bits.view(np.float32)

@@ -125,15 +125,17 @@ def test_cfg2_full_size(dev, full_codec):
     assert torch.equal(ids_s, ids[sub]) and torch.equal(mel_s, mel[sub]) and torch.equal(wav_s, wav[sub])
     # ragged tail: 15000 samples -> 58 frames -> 14 tokens; the mel is zero behind the valid frames
     assert int(il[-1]) == (15000 // 256) // 4 and torch.all(mel[-1, :, int(il[-1]) * 4:] == 0)
-    # oracle on two sampled items
+    # token ids of ALL 32 items against the oracle (the bit-exact contract; 1.2 GFLOP per item on the CPU)
+    ids_ref, il_ref, pre_ref = ref_cpu.vqgan_encode(sd, cfg, audio, lens, return_prequant=True)
+    n_diff, n_bad, n_tie = near_tie_report(ids, ids_ref, pre_ref)
+    report(f"[ids] cfg2 full size, all {B} items: n_diff={n_diff} n_tie={n_tie} of {ids_ref.numel()}")
+    assert n_bad == 0 and n_diff <= n_tie and torch.equal(il.cpu(), il_ref)
+    # decode side against the oracle (fp32 and float64) on two sampled items
     pick = torch.tensor([3, 17])
-    ids_ref, il_ref, pre_ref = ref_cpu.vqgan_encode(sd, cfg, audio[pick], lens[pick], return_prequant=True)
-    n_diff, n_bad, n_tie = near_tie_report(ids[pick], ids_ref, pre_ref)
-    report(f"[ids] cfg2 full size, 2 sampled items: n_diff={n_diff} n_tie={n_tie} of {ids_ref.numel()}")
-    assert n_bad == 0 and n_diff <= n_tie and torch.equal(il[pick].cpu(), il_ref)
-    wav_ref, mel_ref = ref_cpu.vqgan_decode(sd, cfg, ids_ref, il_ref, noise[pick], voc_sd, h)
-    wav64, mel64 = ref_cpu.vqgan_decode(to64(sd), cfg, ids_ref, il_ref, noise[pick].double(), to64(voc_sd), h)
-    wav_g, mel_g = codec.decode(ids_ref.to(dev), il_ref.to(dev), return_audios=True, noise=n_d[pick])
+    ids_p, il_p = ids_ref[pick], il_ref[pick]
+    wav_ref, mel_ref = ref_cpu.vqgan_decode(sd, cfg, ids_p, il_p, noise[pick], voc_sd, h)
+    wav64, mel64 = ref_cpu.vqgan_decode(to64(sd), cfg, ids_p, il_p, noise[pick].double(), to64(voc_sd), h)
+    wav_g, mel_g = codec.decode(ids_p.to(dev), il_p.to(dev), return_audios=True, noise=n_d[pick])
     assert_close_to_truth(mel_g, mel_ref, mel64, "cfg2 full-size mel")
     assert_close_to_truth(wav_g, wav_ref, wav64, "cfg2 full-size waveform")
 
@@ -161,6 +163,32 @@ def test_cfg4_large_vocoder_batch16(dev):
     ref64 = ref_cpu.bigvgan_forward(to64(sd), dict(h), mel[9:10].double())
     assert float((ref.abs() >= 1.0).float().mean()) < 0.01 and float(ref.abs().mean()) > 1e-4      # neither saturated nor dead
     assert_close_to_truth(y[9:10], ref, ref64, "bigvgan 112 M, batch 16 x 94")
+
+
+def test_cfg4_44khz_vocoder_batch16(dev):
+    """BASELINE config 4 as worded: "BigVGAN-large 44.1 kHz with anti-aliased Snake / AMP blocks, batch 16": the v2 44 kHz 128-band 512x
+    model (122 M parameters) at batch 16 x 94 frames (48128 samples per item): determinism, batch independence, and one item against the
+    oracle in fp32 and float64."""
+    from dmel_codec_amd.configs import bigvgan_h
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    h = bigvgan_h("v2_44k_128band_512x")
+    torch.manual_seed(51)
+    m = BigVGAN(h)
+    randomise(m, 52, scale=0.7)
+    with torch.no_grad():
+        m.conv_post.weight_g.fill_(0.004)           # no tanh in the v2 models: keep the random net inside the final clamp(-1, 1)
+    sd = cpu_sd(m)
+    g = torch.Generator().manual_seed(53)
+    mel = torch.randn(16, 128, 94, generator=g)
+    m = m.to(dev)
+    y = m(mel.to(dev))
+    assert y.shape == (16, 1, 94 * math.prod(h.upsample_rates)) == (16, 1, 48128) and torch.isfinite(y).all()
+    assert torch.equal(y, m(mel.to(dev)))
+    assert torch.equal(m(mel[5:7].to(dev)), y[5:7])
+    ref = ref_cpu.bigvgan_forward(sd, dict(h), mel[11:12])
+    ref64 = ref_cpu.bigvgan_forward(to64(sd), dict(h), mel[11:12].double())
+    assert float((ref.abs() >= 1.0).float().mean()) < 0.01 and float(ref.abs().mean()) > 1e-4      # neither saturated nor dead
+    assert_close_to_truth(y[11:12], ref, ref64, "bigvgan 122 M 44.1 kHz, batch 16 x 94")
 
 
 @pytest.mark.parametrize("orig,new", [(16000, 24000), (44100, 24000), (48000, 24000), (22050, 24000), (24000, 16000)])

@@ -391,10 +391,13 @@ def test_bigvgan_ampblock2_golden(dev, golden):
 def assert_close_to_truth(y, ref32, ref64, what=""):
     """Deep random-weight stacks amplify rounding noise: the fp32 oracle itself moves by 3-5e-5 relative when only
     its thread count (oneDNN blocking) changes.  So whole-network outputs are judged against the SAME oracle run in
-    float64: the kernel must be within 1e-4 of the truth or within 3x the fp32 oracle's own distance from it."""
-    e_gpu, e_ref = rel_err(y, ref64), rel_err(ref32, ref64)
+    float64: the kernel must be within 1e-4 of the truth or within 3x the fp32 oracle's own distance from it.  Every call puts its
+    three numbers on record (gpurun_out/parity_report.txt -> profiles/): how much of the allowance is used is visible, not assumed."""
+    e_gpu, e_ref, e_32 = rel_err(y, ref64), rel_err(ref32, ref64), rel_err(y, ref32)
+    report(f"[truth] {what}: gpu-vs-fp64 {e_gpu:.2e}, oracle-fp32-vs-fp64 {e_ref:.2e}, gpu-vs-oracle-fp32 {e_32:.2e}")
     assert e_gpu < max(TOL, 3.0 * e_ref), f"{what}: gpu-vs-fp64 {e_gpu:.2e}, oracle-fp32-vs-fp64 {e_ref:.2e}"
-    assert rel_err(y, ref32) < 4.0 * max(TOL, e_ref), what      # two fp32 results can sit on opposite sides of the truth
+    # (round 2 also allowed the two fp32 results 4x max(TOL, e_ref) of each other: that bound follows from the one above by the triangle
+    # inequality -- e_32 <= e_gpu + e_ref -- and is no longer asserted separately; e_32 is on record instead)
 
 
 def to64(sd):
@@ -1336,3 +1339,35 @@ def test_full_training_step_matches_cpu_reference_loop(dev):
     for k, v in dsd.items():
         assert rel_err(after["discriminator." + k], v.detach()) < 3e-3, (k, rel_err(after["discriminator." + k], v.detach()))
         assert (after["discriminator." + k].double() - v.detach()).abs().mean() < 2e-5, k
+
+
+def test_f16_split_debug_range_check_is_loud(dev):
+    """DMEL_DEBUG_F16_RANGE=1 (include/dmel_hip.h, DMEL_PRECISION_FP32_F16X2): a launch whose input leaves the fp16 split's domain
+    (|x| >= 2^6 * 65504) fails with an error instead of producing inf; inside the domain nothing changes.  The switch is read once per
+    process, hence the child process."""
+    import subprocess, sys, os, textwrap
+    from conftest import ROOT
+    code = textwrap.dedent("""
+        import ctypes as C, torch
+        from dmel_codec_amd import _lib
+        L = _lib.lib()
+        h = C.c_void_p()
+        w = torch.randn(32, 32, 3) * 0.1
+        _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), None, 32, 32, 3, 1))
+        _lib.check(L.dmel_conv_set_precision(h, 3))
+        x = torch.randn(2, 32, 200, device="cuda")
+        y = torch.empty_like(x)
+        _lib.check(L.dmel_conv_forward(h, x.data_ptr(), y.data_ptr(), 2, 200, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        assert torch.isfinite(y).all()
+        x[1, 7, 100] = 5.0e6
+        try:
+            _lib.check(L.dmel_conv_forward(h, x.data_ptr(), y.data_ptr(), 2, 200, _lib.stream_ptr()))
+            print("NOT-REFUSED")
+        except RuntimeError as e:
+            print("REFUSED" if "outside the documented domain" in str(e) else "OTHER " + str(e))
+    """)
+    env = dict(os.environ, DMEL_DEBUG_F16_RANGE="1", PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "REFUSED", out.stdout + out.stderr[-1000:]

@@ -4,7 +4,9 @@ implicit-GEMM convolution, including the whole-stack WaveNet kernel), with the g
 the bytes of a wide coalesced read: doubled; WRITE_SIZE exact; counter unit KB).
 
     python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
-import csv, json, sys
+import csv, json, os, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from collections import defaultdict
 
 
@@ -38,9 +40,10 @@ def main():
            "writes_bytes_per_launch": round(write_kb / max(1, launches_w) * 1024),
            "launches_in_profile": launches,
            "algorithmic_bytes_per_launch": None,
+           "kernel_source_hash": __import__("bench").kernel_source_hash(),     # bench.py flags the figure as stale when the kernels change
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over `bench.py --steps 2 --warmup 1 --cpu-budget 0 "
                      "--median-steps 0 --streams 1`; conv family = conv_bf16_kernel<...> + wavenet_fused_kernel; FETCH_SIZE doubled "
-                     "(gfx950 reports half of a wide coalesced read), WRITE_SIZE exact, KB -> bytes; profiles/r02_pmc_*.csv",
+                     "(gfx950 reports half of a wide coalesced read), WRITE_SIZE exact, KB -> bytes; profiles/r03_pmc_*.csv",
            "top_kernels": table}
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
