@@ -70,6 +70,12 @@ struct SegRun {
   // fp16-split launches over a GRADIENT tensor (single segment): bit pattern of its max |value| in device memory (launch_absmax on the same
   // stream); the kernel stages x * 2^(13 - exponent) instead of x * 2^-6 and undoes it on the accumulators.  nullptr: activations.
   const uint32_t* in_absmax = nullptr;
+  // Pre-split operand (fp16-split launches only): the input ALREADY as two planes of fp16 pieces in the kernel's B-fragment order,
+  // [piece][b][channel / 8][t] x (8 x fp16 = 16 bytes), values x 2^-6, second piece x 2^11 -- what the staging code would have produced.
+  // Written by the producing kernel's epilogue (ConvRun::yp) or by launch_split_planes.  The staging pass then copies 16-byte units
+  // instead of converting 8 floats per unit, once per row block of the weights.  xp != nullptr: x is ignored; channels % 8 == 0.
+  const void* xp = nullptr;
+  int64_t xp_plane = 0;      // 16-byte units between the two planes (= B * channels / 8 * T)
 };
 
 struct ConvRun {
@@ -95,9 +101,17 @@ struct ConvRun {
   // each followed by fold_pitch - fold_valid ZERO columns that play the role of the convolution's zero padding): outputs in the gap
   // columns are written as zeros so the invariant survives the layer.  0 = off.
   int fold_pitch = 0, fold_valid = 0;
+  // paired modes (GATE / RESSKIP): write the result (also: yp_only = instead of y) as pre-split planes [piece][b][C / 8][Tcols], for the
+  // convolution that consumes it (SegRun::xp).  C % 8 == 0.
+  void* yp = nullptr;
+  int64_t yp_plane = 0;
+  int yp_only = 0;
 };
 
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream);
+// x (B, C, T) fp32 -> the two pre-split planes (SegRun::xp layout), columns at or behind len[b / len_div] written as zero; C % 8 == 0
+int launch_split_planes(const float* x, void* planes, int64_t plane_units, const int64_t* len, int len_div, int B, int C, int64_t T,
+                        hipStream_t stream);
 
 // ---- host packing (template, header-only) ---------------------------------------------------
 template <class FW, class FB> int pack_conv(PackedConv& pc, const PackDesc& d, FW get_w, FB get_b) {

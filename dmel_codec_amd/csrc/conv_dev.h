@@ -14,6 +14,10 @@ struct SegArgs {
   float in_scale;
   int Cin, nchunk, taps, dil, pad_left, tstride, toff;
   const uint32_t* in_absmax;    // fp16 split over a gradient tensor (segment 0 only): see conv.h SegRun
+  // Pre-split input (conv.h SegRun::xp): the operand already as two fp16 planes in B-fragment order, [piece][b][channel / 8][t] x 16 bytes
+  const uint4* xp;
+  int64_t xp_plane;             // uint4 between the two pieces
+  int xp_g8;                    // 8-channel groups per batch item
 };
 
 struct KArgs {
@@ -36,6 +40,10 @@ struct KArgs {
   const int64_t* out_len;
   float* skip;
   int fold_pitch, fold_valid;
+  // paired modes: also (yp_only: instead) write the output as pre-split fp16 planes for the convolution that reads it next
+  uint4* yp;
+  int64_t yp_plane;
+  int yp_g8, yp_only;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) {
@@ -159,31 +167,59 @@ __device__ __forceinline__ void conv_epilogue(const KArgs& a, floatx16 (&acc)[MT
     bool gap[NT];
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni) gap[ni] = in_gap(a, colbase + ni * 32);
+    typedef _Float16 ep_f16x2 __attribute__((ext_vector_type(2)));
+    typedef float ep_f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
       const int mtile = mrow0 + mi * 32;
       if (mtile >= a.mtiles * 32) continue;
       const int q32 = mtile >> 5;
+      // A lane holds, of each 8-channel group of the tile, FOUR consecutive channels (4 h .. 4 h + 3: accumulator registers r0 .. r0 + 3,
+      // partner rows in r0 + 4 .. r0 + 7), i.e. one 8-byte half of the group's 16-byte unit in the pre-split plane layout.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        if ((r >> 2) & 1) continue;  // odd 4-groups are the partner rows (filter / skip)
-        const int rho = (r & 3) + 8 * (r >> 2) + 4 * h;
-        const int c = q32 * 16 + ((rho >> 3) >> 1) * 8 + (rho & 7);
-        if (c >= a.C) continue;
-        const float b0 = a.bias[mtile + rho], b1 = a.bias[mtile + rho + 8];
-        float* yrow = yb + c * ycs;
-        float* srow = (MODE == EPI_RESSKIP) ? sb + c * ycs : nullptr;
+      for (int gs = 0; gs < 2; ++gs) {
+        const int r0 = gs * 8;
+        const int c0 = q32 * 16 + gs * 8 + 4 * h;
+        if (c0 >= a.C) continue;
+        float b0[4], b1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int rho = j + 8 * (r0 >> 2) + 4 * h;
+          b0[j] = a.bias[mtile + rho];
+          b1[j] = a.bias[mtile + rho + 8];
+        }
 #pragma unroll
         for (int ni = 0; ni < NT; ++ni) {
           const int q = colbase + ni * 32;
           if (q >= tcols) continue;
-          const float v0 = acc[mi][ni][r] + b0;
-          const float v1 = acc[mi][ni][(r + 4) & 15] + b1;
-          if (MODE == EPI_GATE) {
-            yrow[q] = gap[ni] ? 0.f : (1.f / (1.f + expf(-v0))) * tanhf(v1);
-          } else {
-            yrow[q] = gap[ni] ? 0.f : (yrow[q] + v0) / 1.41421356237309504880f;
-            srow[q] = gap[ni] ? 0.f : (a.skip_first ? v1 : srow[q] + v1);
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            o[j] = 0.f;
+            if (c0 + j >= a.C) continue;
+            const float v0 = acc[mi][ni][r0 + j] + b0[j];
+            const float v1 = acc[mi][ni][r0 + j + 4] + b1[j];
+            float* yrow = yb + (c0 + j) * ycs;
+            if (MODE == EPI_GATE) {
+              o[j] = gap[ni] ? 0.f : (1.f / (1.f + expf(-v0))) * tanhf(v1);
+              if (!a.yp_only) yrow[q] = o[j];
+            } else {
+              float* srow = sb + (c0 + j) * ycs;
+              o[j] = gap[ni] ? 0.f : (yrow[q] + v0) / 1.41421356237309504880f;
+              yrow[q] = o[j];
+              srow[q] = gap[ni] ? 0.f : (a.skip_first ? v1 : srow[q] + v1);
+            }
+          }
+          if (a.yp) {
+            // the operand split of conv_bf16_kernel<NP = 2>::store_x, done once here instead of once per row block of the reader
+#pragma clang fp contract(off)
+            const float s0 = o[0] * kF16XScale, s1 = o[1] * kF16XScale, s2 = o[2] * kF16XScale, s3 = o[3] * kF16XScale;
+            const ep_f16x2 h01 = __builtin_convertvector((ep_f32x2){s0, s1}, ep_f16x2), h23 = __builtin_convertvector((ep_f32x2){s2, s3}, ep_f16x2);
+            const ep_f16x2 l01 = __builtin_convertvector((ep_f32x2){(s0 - (float)h01[0]) * kF16LoScale, (s1 - (float)h01[1]) * kF16LoScale}, ep_f16x2);
+            const ep_f16x2 l23 = __builtin_convertvector((ep_f32x2){(s2 - (float)h23[0]) * kF16LoScale, (s3 - (float)h23[1]) * kF16LoScale}, ep_f16x2);
+            uint2* dst = reinterpret_cast<uint2*>(a.yp + ((int64_t)b * a.yp_g8 + (c0 >> 3)) * tcols + q) + h;
+            *dst = make_uint2(__builtin_bit_cast(uint32_t, h01), __builtin_bit_cast(uint32_t, h23));
+            *(dst + 2 * a.yp_plane) = make_uint2(__builtin_bit_cast(uint32_t, l01), __builtin_bit_cast(uint32_t, l23));
           }
         }
       }

@@ -369,6 +369,12 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 #ifndef DMEL_PD2
 #define DMEL_PD2 2  // ... of the fp16-split kernel (half the MFMA time per step)
 #endif
+#ifndef DMEL_XTOP
+// 1: issue the next chunk's x loads at the TOP of a chunk's first step, in front of that step's weight prefetch (two steps of MFMAs between
+// issue and use instead of one).  Round-3 experiment, A/B'd interleaved on one device against 0 (profiles/r03_conv_experiments.txt): no
+// shape gained (-4 .. +2 %), with or without a weight prefetch distance of 3 -- the x loads are not what the waves wait for.  Stays 0.
+#define DMEL_XTOP 0
+#endif
 #ifndef DMEL_KG2
 #define DMEL_KG2 2  // 8-channel groups staged per barrier by the fp16-split kernel when the convolution has taps
 #endif
@@ -379,8 +385,9 @@ __device__ __forceinline__ uint32_t pack_hi16(float lo, float hi) {      // {bf1
 
 // (amdgpu_waves_per_eu(2, 2) -- 166 VGPRs, accumulators out of the AGPRs -- was measured: 2-12 % slower on every bench shape, and the
 // allocator still parks one weight set on the B-fragment registers; the default register budget stays.)
-template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO, int NP, int KG>
+template <int WAVES_M, int WAVES_N, int MT, int NT, int MODE, int HALO, int NP, int KG, int PS = 0>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_bf16_kernel(KArgs a) {
+  static_assert(PS == 0 || NP == 2, "pre-split inputs exist for the fp16 split only");
   constexpr int BM = WAVES_M * MT * 32, BN = WAVES_N * NT * 32;
   constexpr int XS = BN + HALO;
   constexpr int SUB = KG / 2;                            // 16-channel K steps (per tap) per staged chunk
@@ -447,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
       for (int p = 0; p < NP; ++p) dst[mi][p] = *reinterpret_cast<const uint4*>(sp + p * 1024 + lane16);
     }
   };
-  float xr[NIT][8];
+  float xr[NIT][8];       // PS: the same registers hold the two 16-byte units (hi, lo) of an item
 
   // valid input length per segment, read once (a global load inside the K loop would drain the weight prefetch behind it)
   auto seg_limit = [&](int sg) {
@@ -470,6 +477,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
   const int st_kg0 = (wave_u / SEG) * RPW, st_j0 = (wave_u % SEG) * SL;
   auto load_x = [&](int sg, int chunk) {
+    if constexpr (PS != 0) {
+      // pre-split input: an item is two 16-byte loads (hi and lo unit of (8-channel group, column)) and no arithmetic
+      const int taps = a.seg[sg].taps, dil = a.seg[sg].dil;
+      const int wx = BN + (taps - 1) * dil;
+      const int tin = (int)a.seg[sg].Tin, g8 = a.seg[sg].xp_g8;
+      const int lim = sg == 0 ? lim0 : lim1;
+      const int tau0 = q0 + a.seg[sg].toff - a.seg[sg].pad_left;
+      const uint4* xpb = a.seg[sg].xp + (int64_t)b * g8 * tin;
+#pragma unroll
+      for (int rr = 0; rr < RPW; ++rr) {
+        const int kgi = chunk * KG + st_kg0 + rr;                              // scalar: the item's 8-channel group
+        const uint4* rowp = xpb + (int64_t)min(kgi, g8 - 1) * tin;
+#pragma unroll
+        for (int ps = 0; ps < NPASS; ++ps) {
+          const int it = rr * NPASS + ps;
+          const int j = min(st_j0 + ps * 64 + lane, XS - 1);
+          const int tau = tau0 + j;
+          xok[it] = (j < wx) && (tau >= 0) && (tau < lim) && (kgi < g8);
+          const uint4* ptr = rowp + min(max(tau, 0), tin - 1);
+          const uint4 hi = *ptr, lo = *(ptr + a.seg[sg].xp_plane);
+          xr[it][0] = __uint_as_float(hi.x); xr[it][1] = __uint_as_float(hi.y); xr[it][2] = __uint_as_float(hi.z); xr[it][3] = __uint_as_float(hi.w);
+          xr[it][4] = __uint_as_float(lo.x); xr[it][5] = __uint_as_float(lo.y); xr[it][6] = __uint_as_float(lo.z); xr[it][7] = __uint_as_float(lo.w);
+        }
+      }
+      return;
+    }
     const char* xb = reinterpret_cast<const char*>(a.seg[sg].x + (int64_t)b * a.seg[sg].bstride);
     const int taps = a.seg[sg].taps, dil = a.seg[sg].dil, tstride = a.seg[sg].tstride, Cin = a.seg[sg].Cin;
     const int wx = BN + (taps - 1) * dil;
@@ -497,9 +530,25 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     }
   };
   auto store_x = [&](uint4* dst, int sg, int chunk) {
+#pragma clang fp contract(off)
+    if constexpr (PS != 0) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int rr = it / NPASS, ps = it % NPASS;
+        const int jl = ps * 64 + lane;
+        const int j = st_j0 + jl;
+        if ((SL % 64 != 0 && jl >= SL) || (XS % SL != 0 && j >= XS)) continue;
+        const int i = (st_kg0 + rr) * XS + j;
+        const bool ok = xok[it];
+        dst[i] = make_uint4(ok ? __float_as_uint(xr[it][0]) : 0u, ok ? __float_as_uint(xr[it][1]) : 0u, ok ? __float_as_uint(xr[it][2]) : 0u,
+                            ok ? __float_as_uint(xr[it][3]) : 0u);
+        dst[PSZ + i] = make_uint4(ok ? __float_as_uint(xr[it][4]) : 0u, ok ? __float_as_uint(xr[it][5]) : 0u, ok ? __float_as_uint(xr[it][6]) : 0u,
+                                  ok ? __float_as_uint(xr[it][7]) : 0u);
+      }
+      return;
+    }
     // No contraction in here: the scaled input is ROUNDED to fp32 and then split.  Fused into the first subtraction of the split (fma), the
     // pieces would sum to the unrounded product, and the whole-stack WaveNet kernel, which rounds, would differ in the last bit.
-#pragma clang fp contract(off)
     const float scale = NP == 2 ? a.seg[sg].in_scale * f16_in : a.seg[sg].in_scale;
     const int Cin = a.seg[sg].Cin;
 #pragma unroll
@@ -591,6 +640,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   // (Register double-buffering of the x fragments was tried and dropped: the ds_read latency hides behind the other wave.)
   constexpr int kWLoads = MT * NP;                                              // weight loads per step and wave
   constexpr int kWaitW = (kWLoads & 15) | (7 << 4) | (15 << 8) | ((kWLoads >> 4) << 14);   // s_waitcnt vmcnt(kWLoads)
+  constexpr int kXLoads = NIT * (PS != 0 ? 2 : 8);                                          // x loads per thread and chunk
+  constexpr int kWX = kWLoads + kXLoads < 63 ? kWLoads + kXLoads : 63;
+  constexpr int kWaitWX = (kWX & 15) | (7 << 4) | (15 << 8) | ((kWX >> 4) << 14);           // ... that also leaves a chunk of x loads in flight
   auto k_step = [&](auto R, int s) {
     constexpr int r = decltype(R)::value;
     uint4 (&use)[MT][NP] = wa[r % (PD + 1)];
@@ -603,6 +655,18 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
       else newx = (nc16 % SUB) == 0;
     }
     const bool has_next = s + 1 < a.steps;
+#if DMEL_XTOP
+    // x loads of the NEXT chunk at the TOP of a chunk's first step, in front of this step's weight prefetch.  vmcnt retires in order: the wait
+    // for the weights of step s + 1 at the end of this step may leave these loads (and the weights of step s + 2) in flight, and only the
+    // wait at the end of step s + 1 -- for weights issued AFTER them -- forces them home.  Issued at the END of the step (as before) they
+    // sat behind one step of MFMAs only: ~300 cycles against an L2 / Infinity-Cache latency of 500-900, the rest a stall in every chunk.
+    bool x_younger = false;
+    if (cstep == 0) {
+      pending = next_chunk(sg, c16 / SUB, psg, pck);
+      if (pending && !(DMEL_EXP & 2)) { load_x(psg, pck); x_younger = !newx; }
+      if (DMEL_EXP & 2) pending = false;
+    }
+#endif
     // unconditional (the last PD steps re-fetch the final step's fragments into a set nobody reads again): a branch here
     // would put a wait-free path into the CFG and with it a conservative vmcnt(0) in front of the MFMAs
     if (!(DMEL_EXP & 4)) load_w(wa[(r + PD) % (PD + 1)], min(s + PD, a.steps - 1));
@@ -636,12 +700,17 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
                                                                     bcur[ni][NP == 3 ? PB[t] : 0], acc[mi][ni], 0, 0, 0);
       }
     }
+#if DMEL_XTOP
+    if (x_younger) __builtin_amdgcn_s_waitcnt(kWaitWX);      // the weights of step s + 1 are older than the x loads: those may stay in flight
+    else __builtin_amdgcn_s_waitcnt(kWaitW);
+#else
     __builtin_amdgcn_s_waitcnt(kWaitW);
     if (cstep == 0) {
       pending = next_chunk(sg, c16 / SUB, psg, pck);
       if (pending && !(DMEL_EXP & 2)) load_x(psg, pck);
       if (DMEL_EXP & 2) pending = false;
     }
+#endif
     if (pending && (((DMEL_EXP & 1) ? false : cstep == 1) || newx)) {       // second step of the chunk, or its only one
       store_x(Xb + (xbuf ^ 1) * (NP * PSZ), psg, pck);
       pending = false;
@@ -678,7 +747,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   conv_epilogue<MT, NT, MODE, NP == 2 ? 8 : 4>(a, acc, mblk * BM + wave_m * (MT * 32), q0 + wave_n * (NT * 32) + l31, b, lb, h);
 }
 
-template <int WM, int WN, int MT, int NT, int MODE, int HALO, int NP, int KG>
+template <int WM, int WN, int MT, int NT, int MODE, int HALO, int NP, int KG, int PS = 0>
 static int launch_b16k(const KArgs& ka, int B, int mblocks, hipStream_t st) {
   constexpr int BN = WN * NT * 32;
   constexpr size_t lds = (size_t)2 * NP * KG * (BN + HALO) * 16;
@@ -686,7 +755,7 @@ static int launch_b16k(const KArgs& ka, int B, int mblocks, hipStream_t st) {
   KArgs k2 = ka;
   dim3 grid;
   DMEL_TRY(conv_grid(k2, (int)((ka.Tcols + BN - 1) / BN), mblocks, B, grid));
-  hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, MODE, HALO, NP, KG>), grid, dim3(64 * WM * WN), lds, st, k2);
+  hipLaunchKernelGGL((conv_bf16_kernel<WM, WN, MT, NT, MODE, HALO, NP, KG, PS>), grid, dim3(64 * WM * WN), lds, st, k2);
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
 }
@@ -736,6 +805,23 @@ static int pick_tile_bf16(int mtiles, int64_t T, int np, int steps) {
   if (mtiles >= 4) return (T > 2048 && np != 2) ? 4 : 1;
   if (mtiles >= 2) return 2;
   return 3;
+}
+
+// Pre-split inputs (SegRun::xp; the decoder WaveNet's gate and residual / skip convolutions): the fp16-split kernel with a staging pass
+// that copies 16-byte units.  Instantiated for the tiles those layers use: 128 x 96 (short rows) and the eight-wave 256 x 96.
+template <int MODE> static int launch_presplit(const KArgs& ka, int B, int64_t Tcols, hipStream_t st) {
+  int halo = 0;
+  for (int s = 0; s < ka.nseg; ++s) halo = std::max(halo, (ka.seg[s].taps - 1) * ka.seg[s].dil);
+  if (halo > 16) { set_error("conv (pre-split input): receptive field %d exceeds the 16-column halo built for this path", halo); return DMEL_EUNSUPPORTED; }
+  const bool wide = ka.mtiles >= 8 && Tcols > 96;
+  if (wide) {
+    const int mblocks = (ka.mtiles * 32 + 255) / 256;
+    if (halo == 0) return launch_b16k<8, 1, 1, 3, MODE, 0, 2, 4, 1>(ka, B, mblocks, st);
+    return launch_b16k<8, 1, 1, 3, MODE, 16, 2, DMEL_KG2, 1>(ka, B, mblocks, st);
+  }
+  const int mblocks = (ka.mtiles * 32 + 127) / 128;
+  if (halo == 0) return launch_b16k<4, 1, 1, 3, MODE, 0, 2, 4, 1>(ka, B, mblocks, st);
+  return launch_b16k<4, 1, 1, 3, MODE, 16, 2, DMEL_KG2, 1>(ka, B, mblocks, st);
 }
 
 template <int NP> static int launch_bf16_any(const KArgs& ka, EpiMode mode, int B, int64_t Tcols, hipStream_t st) {
@@ -817,6 +903,44 @@ template <int MODE> static int launch_mode(const KArgs& ka, int tile, int B, hip
   }
 }
 
+// x (B, C, T) fp32 -> pre-split planes [piece][b][C / 8][T] x 16 bytes (SegRun::xp): the operand split of store_x, once per element
+__global__ __launch_bounds__(256) void split_planes_kernel(const float* __restrict__ x, uint4* __restrict__ planes, int64_t plane_units,
+                                                           const int64_t* __restrict__ len, int len_div, int C, int T) {
+  const int b = blockIdx.z, g = blockIdx.y;
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= T) return;
+  const float* xr = x + ((int64_t)b * C + g * 8) * T + t;
+  const bool live = !len || t < len[b / len_div];
+  float v[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) v[e] = live ? xr[(int64_t)e * T] : 0.f;
+  f16x8 ph, pl;
+  {
+#pragma clang fp contract(off)
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      const float s0 = v[e] * kF16XScale, s1 = v[e + 1] * kF16XScale;
+      const f16x2 hi = __builtin_convertvector((f32x2){s0, s1}, f16x2);
+      const f16x2 lo = __builtin_convertvector((f32x2){(s0 - (float)hi[0]) * kF16LoScale, (s1 - (float)hi[1]) * kF16LoScale}, f16x2);
+      ph[e] = hi[0]; ph[e + 1] = hi[1];
+      pl[e] = lo[0]; pl[e + 1] = lo[1];
+    }
+  }
+  const int64_t i = ((int64_t)b * (C / 8) + g) * T + t;
+  planes[i] = __builtin_bit_cast(uint4, ph);
+  planes[plane_units + i] = __builtin_bit_cast(uint4, pl);
+}
+int launch_split_planes(const float* x, void* planes, int64_t plane_units, const int64_t* len, int len_div, int B, int C, int64_t T,
+                        hipStream_t stream) {
+  DMEL_CHECK_ARG(x && planes && B > 0 && B <= 65535 && C > 0 && C % 8 == 0 && C / 8 <= 65535 && T > 0 && T < ((int64_t)1 << 30), "split_planes: bad argument");
+  ProfScope ps("small", stream, 0.0, 8.0 * B * C * (double)T);
+  hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)((T + 255) / 256), (unsigned)(C / 8), (unsigned)B), dim3(256), 0, stream, x,
+                     reinterpret_cast<uint4*>(planes), plane_units, len, len_div > 0 ? len_div : 1, C, (int)T);
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   KArgs ka{};
   const PackDesc& d = pc.d;
@@ -826,7 +950,11 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   for (int s = 0; s < d.nseg; ++s) {
     const SegDesc& sd = d.seg[s];
     SegArgs& o = ka.seg[s];
-    DMEL_CHECK_ARG(r.seg[s].x != nullptr, "conv: input pointer of segment %d is NULL", s);
+    DMEL_CHECK_ARG(r.seg[s].x != nullptr || r.seg[s].xp != nullptr, "conv: input pointer of segment %d is NULL", s);
+    DMEL_CHECK_ARG(r.seg[s].xp == nullptr || (r.precision == DMEL_PRECISION_FP32_F16X2 && sd.Cin % 8 == 0 && sd.tstride == 1 &&
+                                              r.seg[s].in_scale == 1.f && r.seg[s].tshift == 0 && r.seg[s].in_absmax == nullptr && r.fold_pitch == 0),
+                   "conv: a pre-split input needs the fp16-split precision, channels %% 8 == 0, unit stride and scale");
+    DMEL_CHECK_ARG((r.seg[s].xp != nullptr) == (r.seg[0].xp != nullptr), "conv: either every input segment is pre-split or none is");
     // taps on a strided view (polyphase branches of a stride-2 convolution: the discriminator) are staged correctly by the bf16
     // matrix-core kernels only; the native fp32-MFMA kernels were never built for it
     DMEL_CHECK_ARG(sd.taps == 1 || sd.tstride == 1 || (r.precision != DMEL_PRECISION_FP32_MFMA && !getenv("DMEL_CONV_FP32_MFMA")),
@@ -834,6 +962,7 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     o.x = r.seg[s].x; o.bstride = r.seg[s].bstride; o.cstride = r.seg[s].cstride; o.Tin = r.seg[s].Tin;
     o.in_len = r.seg[s].in_len; o.in_scale = r.seg[s].in_scale;
     o.in_absmax = (s == 0 && d.nseg == 1 && r.precision == DMEL_PRECISION_FP32_F16X2) ? r.seg[s].in_absmax : nullptr;
+    o.xp = reinterpret_cast<const uint4*>(r.seg[s].xp); o.xp_plane = r.seg[s].xp_plane; o.xp_g8 = sd.Cin / 8;
     o.Cin = sd.Cin; o.nchunk = (sd.Cin + kCK - 1) / kCK; o.taps = sd.taps; o.dil = sd.dil;
     o.pad_left = sd.pad_left; o.tstride = sd.tstride; o.toff = sd.toff + (int)(r.seg[s].tshift * sd.tstride);
     max_halo = std::max(max_halo, (sd.taps - 1) * sd.dil);
@@ -855,6 +984,8 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   ka.res = r.res; ka.res_bs = r.res_bs; ka.res_cs = r.res_cs; ka.row_scale = r.row_scale;
   ka.out_len = r.out_len; ka.skip = r.skip;
   ka.fold_pitch = r.fold_pitch; ka.fold_valid = r.fold_valid;
+  DMEL_CHECK_ARG(r.yp == nullptr || (d.mode != EPI_LINEAR && d.C % 8 == 0 && r.out_tstride == 1), "conv: pre-split output needs a paired mode and C %% 8 == 0");
+  ka.yp = reinterpret_cast<uint4*>(r.yp); ka.yp_plane = r.yp_plane; ka.yp_g8 = d.C / 8; ka.yp_only = r.yp_only;
   DMEL_CHECK_ARG(r.fold_pitch == 0 || (r.fold_pitch >= r.fold_valid && r.fold_valid > 0 && r.B == 1 && r.out_tstride == 1),
                  "conv: folded-batch launches are single-item, unit-stride and need 0 < fold_valid <= fold_pitch");
   DMEL_CHECK_ARG((int64_t)d.C * ka.y_cs < ((int64_t)1 << 31) && ka.Tout < ((int64_t)1 << 30) && ka.Tcols < ((int64_t)1 << 30),
@@ -881,6 +1012,11 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     return launch_bf16_any<1>(ka, d.mode, r.B, r.Tcols, stream);
   // fp32: the split kernel is the default everywhere (after the wait-placement fixes it also wins on the 32-row, K < 128
   // layers of the last vocoder stage: 58 vs 72 us); the native fp32-MFMA kernels serve DMEL_PRECISION_FP32_MFMA
+  if (r.seg[0].xp != nullptr) {
+    DMEL_CHECK_ARG(!native_fp32 && train_precision_override() != DMEL_PRECISION_BF16 && d.mode != EPI_LINEAR,
+                   "conv: pre-split inputs are built for the paired modes of the fp16-split kernel");
+    return d.mode == EPI_GATE ? launch_presplit<EPI_GATE>(ka, r.B, r.Tcols, stream) : launch_presplit<EPI_RESSKIP>(ka, r.B, r.Tcols, stream);
+  }
   if (r.precision == DMEL_PRECISION_FP32_F16X2 && !native_fp32) {
     // Debug range check of the fp16 split's documented domain (include/dmel_hip.h: activations are staged x 2^-6, so |x| must stay below
     // 2^6 * 65504 = 4.19e6; beyond that the first piece overflows to inf).  DMEL_DEBUG_F16_RANGE=1: reduce max |x| of every contiguous

@@ -377,7 +377,7 @@ static FoldGeom wavenet_fold(const dmel_wavenet* m, int N, int64_t T) {
   return f;
 }
 
-struct WavePlan { float *xb, *zb, *sb, *tb, *cf, *xin, *yf; size_t bytes; };
+struct WavePlan { float *xb, *zb, *sb, *tb, *cf, *xin, *yf; void *xp, *zp, *cp; size_t bytes; };
 static WavePlan wavenet_plan(const dmel_wavenet* m, int N, int64_t T, void* ws) {
   Arena a(ws, (size_t)-1);
   WavePlan p{};
@@ -387,6 +387,10 @@ static WavePlan wavenet_plan(const dmel_wavenet* m, int N, int64_t T, void* ws) 
   p.zb = a.take<float>(n);
   p.sb = a.take<float>(n);
   p.tb = m->has_out ? a.take<float>(n) : nullptr;
+  // pre-split operand planes of the fp16-split layered path (as many bytes as the fp32 tensors they shadow)
+  p.xp = a.take<float>(n);
+  p.zp = a.take<float>(n);
+  p.cp = m->Ccond ? a.take<float>((size_t)N * m->Ccond * T) : nullptr;
   if (f.on) {
     p.cf = m->Ccond ? a.take<float>((size_t)m->Ccond * f.pitch) : nullptr;
     p.xin = m->has_in ? a.take<float>((size_t)m->Cin * f.pitch) : nullptr;
@@ -479,16 +483,39 @@ extern "C" int dmel_wavenet_forward(const dmel_wavenet* m, const float* x, const
   } else {
     DMEL_TRY(launch_masked_copy(x, xb, in_lengths, div, N, C, T, st));
   }
+  // DMEL_WAVENET_PRESPLIT=1 (round-3 experiment, off by default): at the fp16-split precision every convolution of the stack reads its
+  // input as PRE-SPLIT fp16 planes -- the condition is split once per forward instead of once per layer and row block (20 x 9 times for
+  // the 560-channel decoder), the gate's output leaves its epilogue as planes only, the residual stream as fp32 + planes -- so that the
+  // staging pass copies 16-byte units instead of converting.  Bit-identical (tests), and NOT faster: gate 114.9 vs 112.8 us, residual /
+  // skip 46.5 vs 49.6 us per launch at 32 x 92 frames (rocprofv3, profiles/r03_conv_experiments.txt).  The operand conversion is not
+  // what these kernels wait for either.
+  const char* ps_env = getenv("DMEL_WAVENET_PRESPLIT");
+  const bool presplit = m->precision == DMEL_PRECISION_FP32_F16X2 && C % 8 == 0 && (m->Ccond % 8) == 0 &&
+                        (m->cycle ? 1 << std::min(m->L - 1, m->cycle - 1) : 1) <= 8 && ps_env && ps_env[0] == '1' && !getenv("DMEL_CONV_FP32_MFMA");
+  const int64_t units = (int64_t)N * (C / 8) * T, cunits = (int64_t)N * (m->Ccond / 8) * T;
+  if (presplit) {
+    DMEL_TRY(launch_split_planes(xb, p.xp, units, nullptr, 1, N, C, T, st));
+    if (m->Ccond) DMEL_TRY(launch_split_planes(condition, p.cp, cunits, nullptr, 1, N, m->Ccond, T, st));
+  }
   for (int i = 0; i < m->L; ++i) {  // wavenet.py:116-135
     ConvRun g = run_1seg(xb, C, T, zb, C, T, N);
     if (m->Ccond) {
       g.seg[1].x = condition; g.seg[1].bstride = (int64_t)m->Ccond * T; g.seg[1].cstride = T; g.seg[1].Tin = T;
     }
     g.precision = m->precision;
+    if (presplit) {
+      g.seg[0].xp = p.xp; g.seg[0].xp_plane = units;
+      if (m->Ccond) { g.seg[1].xp = p.cp; g.seg[1].xp_plane = cunits; }
+      g.yp = p.zp; g.yp_plane = units; g.yp_only = 1;
+    }
     DMEL_TRY(launch_conv(m->gate[i], g, st));
     ConvRun r = run_1seg(zb, C, T, xb, C, T, N);
     r.skip = sb; r.skip_first = (i == 0);
     r.precision = m->precision;
+    if (presplit) {
+      r.seg[0].xp = p.zp; r.seg[0].xp_plane = units;
+      if (i + 1 < m->L) { r.yp = p.xp; r.yp_plane = units; }
+    }
     DMEL_TRY(launch_conv(m->resskip[i], r, st));
   }
   {  // wavenet.py:218-223

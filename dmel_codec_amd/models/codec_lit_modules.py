@@ -362,15 +362,17 @@ class VQGAN(nn.Module):
         return gen_mel
 
     # ------------------------------------------------------------------------------ streaming decode (extension)
-    def streaming_decoder(self, batch: int = 1, feature_lengths: Optional[torch.Tensor] = None, return_audios: bool = True):
+    def streaming_decoder(self, batch: int = 1, feature_lengths: Optional[torch.Tensor] = None, return_audios: bool = True,
+                          graph_chunk_tokens: Optional[int] = None):
         """Incremental decode with state carry (the reference decodes once, after the LM has finished,
         lm_lit_modules.py:467-471): feed token chunks as they arrive with .push(ids (B, G, n)), get audio back as soon as its right
-        context exists; .finish() flushes.  See StreamingDecoder."""
-        return StreamingDecoder(self, batch, feature_lengths, return_audios)
+        context exists; .finish() flushes.  See StreamingDecoder.  graph_chunk_tokens = n: once the stream has reached its steady state, a
+        push of exactly n tokens is ONE HIP-graph replay instead of ~250 launches (an unbounded stream: feature_lengths must be None)."""
+        return StreamingDecoder(self, batch, feature_lengths, return_audios, graph_chunk_tokens)
 
     @torch.no_grad()
     def decode_stream(self, indices, feature_lengths=None, chunk_tokens: int = 64, noise: Optional[torch.Tensor] = None,
-                      return_audios: bool = True):
+                      return_audios: bool = True, use_graph: bool = False):
         """Generator: decode() fed `chunk_tokens` tokens at a time (indices: a (B, G, T4) tensor, or any iterable of (B, G, n) chunks),
         yielding (audio | None, gen_mel) pieces whose concatenation is BIT-identical to decode() on the whole sequence.  The decoder
         WaveNet keeps the output history of every block and only ever computes new columns (dmel_wavenet_stream_step: total work 1.0x);
@@ -387,7 +389,7 @@ class VQGAN(nn.Module):
             batch = first.shape[0]
             import itertools
             chunks = itertools.chain([first], chunks)
-        dec = self.streaming_decoder(batch, feature_lengths, return_audios)
+        dec = self.streaming_decoder(batch, feature_lengths, return_audios, graph_chunk_tokens=chunk_tokens if use_graph else None)
         factor = math.prod(self.quantizer.downsample_factor)
         pos = 0
         for ids in chunks:
@@ -459,9 +461,11 @@ class StreamingDecoder:
 
     QUANT_HALO_TOKENS = 4        # ConvNeXt k7 at rates 2 and 4: 3 / 2 + 3 / 4 tokens of context on each side
 
-    def __init__(self, codec: VQGAN, batch: int, feature_lengths, return_audios: bool):
+    def __init__(self, codec: VQGAN, batch: int, feature_lengths, return_audios: bool, graph_chunk_tokens: Optional[int] = None):
         if codec.decoder is None:
             raise ValueError("Decoder is not loaded")
+        if graph_chunk_tokens is not None and feature_lengths is not None:
+            raise ValueError("graph_chunk_tokens needs an unbounded stream (feature_lengths=None): length masks change from push to push")
         if return_audios and codec.vocoder is None:
             raise ValueError("Vocoder is not loaded")
         self.codec, self.B, self.return_audios = codec, int(batch), return_audios
@@ -487,12 +491,21 @@ class StreamingDecoder:
         self.emitted = 0                    # mel frames handed out
         self.noise_tail = None
         self.finished = False
+        # HIP-graph replay of steady-state pushes (graph_chunk_tokens): a push at batch 1 is ~250 small launches on a mostly idle chip, so
+        # its time is launch count, not arithmetic.  In the steady state every push of n tokens does the same work at the same offsets
+        # RELATIVE to the buffers' origin; with the buffers re-based at the start of every push those offsets are also the same
+        # ADDRESSES, and the whole push -- quantiser window, every WaveNet block's new columns, vocoder window -- is one graph.
+        self._g_n = int(graph_chunk_tokens) if graph_chunk_tokens else None
+        self._rebase = self._g_n is not None      # always move the origin to the oldest column still needed (constant layout)
+        self._graph = None
+        self._g_sig = None                        # what the last eager push of n tokens did; two equal in a row = steady state
+        self.graph_replays = 0
 
     # -- buffers ---------------------------------------------------------------------------------------------------
     def _ensure(self, upto: int, dev) -> None:
         """make room for absolute frames < upto: drop columns nothing will read again, grow if that is not enough"""
         need_from = max(0, min(self.prev[self.L] - self.maxdil, self.emitted - self.voc_halo))
-        if self.cap and upto - self.origin <= self.cap:
+        if self.cap and upto - self.origin <= self.cap and not (self._rebase and need_from > self.origin):
             return
         shift = need_from - self.origin
         keep = max(0, self.z_valid - need_from)
@@ -518,6 +531,74 @@ class StreamingDecoder:
     def push(self, ids: torch.Tensor, noise: Optional[torch.Tensor] = None, final: bool = False):
         """ids (B, G, n) int (n may be 0 with final=True) -> (audio (B, 1, m * up) | None, mel (B, n_mels, m)) for the m >= 0 frames that
         became final with this chunk."""
+        graphable = self._g_n is not None and not final and not self.finished and ids.shape[2] == self._g_n
+        if graphable and self._graph is not None:
+            return self._replay(ids, noise)
+        if graphable and self._g_sig is not None and self._g_sig[0] >= 2:
+            self._capture(ids.device)
+            return self._replay(ids, noise)
+        before = self._state()
+        out = self._push_eager(ids, noise, final)
+        if graphable:
+            # steady state = this push moved every counter by exactly one chunk and left the carried tensors at the same sizes
+            after = self._state()
+            d = tuple(b - a for a, b in zip(before, after))
+            nf = self._g_n * self.factor
+            steady = (d == (self._g_n, self._g_n, nf, nf, nf) + (nf,) * (self.L + 1) and out[1].shape[-1] == nf)
+            sig = (tuple(self.tokens.shape), tuple(self.noise_tail.shape))
+            if steady and self._g_sig is not None and self._g_sig[1] == sig:
+                self._g_sig = (self._g_sig[0] + 1, sig)
+            else:
+                self._g_sig = (1 if steady else 0, sig)
+        return out
+
+    # -- graph replay of steady-state pushes ---------------------------------------------------------------------------
+    def _state(self):
+        return (self.n_tok, self.tok_origin, self.origin, self.z_valid, self.emitted, *self.prev)
+
+    def _set_state(self, st) -> None:
+        self.n_tok, self.tok_origin, self.origin, self.z_valid, self.emitted = st[:5]
+        self.prev = list(st[5:])
+
+    def _capture(self, dev) -> None:
+        f, n = self.factor, self._g_n
+        G = self.tokens.shape[1]
+        self._g_ids = torch.zeros(self.B, G, n, dtype=torch.int32, device=dev)
+        self._g_noise = torch.zeros(self.B, self.C, n * f, dtype=torch.float32, device=dev)
+        # carried tensors become static buffers: the graph reads them, and writes the next push's values back at its end
+        self._g_tok, self._g_tail = self.tokens.contiguous().clone(), self.noise_tail.contiguous().clone()
+        self.tokens, self.noise_tail = self._g_tok, self._g_tail
+        st0 = self._state()
+        torch.cuda.synchronize(dev)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            audio, mel = self._push_eager(self._g_ids, self._g_noise, False)
+            self._g_tok.copy_(self.tokens)
+            self._g_tail.copy_(self.noise_tail)
+        # capture records, it does not run: the counters go back to where they were; every replay then advances them by the same amounts
+        self._g_delta = tuple(b - a for a, b in zip(st0, self._state()))
+        self._set_state(st0)
+        self.tokens, self.noise_tail = self._g_tok, self._g_tail
+        self._g_out = (audio, mel)
+        self._graph = g
+
+    def _replay(self, ids: torch.Tensor, noise: Optional[torch.Tensor]):
+        _lib.require_cuda(ids, "indices")
+        f, n = self.factor, self._g_n
+        self._g_ids.copy_(ids)
+        if noise is None:
+            self._g_noise.normal_()
+        else:
+            if noise.shape != (self.B, self.C, n * f):
+                raise ValueError(f"noise must have shape {(self.B, self.C, n * f)}")
+            self._g_noise.copy_(noise)
+        self._graph.replay()
+        self._set_state(tuple(a + d for a, d in zip(self._state(), self._g_delta)))
+        self.graph_replays += 1
+        audio, mel = self._g_out
+        return (audio.clone() if audio is not None else None), mel.clone()
+
+    def _push_eager(self, ids: torch.Tensor, noise: Optional[torch.Tensor] = None, final: bool = False):
         codec, f = self.codec, self.factor
         if self.finished:
             raise RuntimeError("stream already finished")

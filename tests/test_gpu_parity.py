@@ -253,6 +253,34 @@ def near_tie_report(ids_gpu, ids_ref, pre_ref, eps=2e-4):
     return int(diff.sum()), int((diff & ~tie).sum()), int(tie.sum())
 
 
+@pytest.mark.parametrize("N,T,L,lens", [(3, 92, 4, None), (2, 300, 5, None), (4, 92, 3, [92, 50, 0, 91]), (1, 937, 2, None)])
+def test_decoder_wavenet_with_presplit_operands_is_bit_identical(dev, monkeypatch, N, T, L, lens):
+    """The conditioned 560-channel decoder WaveNet at the fp16-split precision reads every convolution input as pre-split fp16 planes
+    (condition split once per forward, gate output written by its epilogue as planes, residual stream as fp32 + planes) instead of
+    converting in the staging pass once per layer and row block.  Same operand bits -> the output must be torch.equal to the path that
+    converts in the staging pass (DMEL_WAVENET_PRESPLIT=0), on the 128 x 96 and the eight-wave 256 x 96 tiles, with length masks; and
+    within the parity bar of the oracle."""
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    torch.manual_seed(17 + T)
+    m = WaveNet(input_channels=560, output_channels=80, residual_channels=560, residual_layers=L, dilation_cycle=4, condition_channels=560)
+    randomise(m, 18)
+    m.set_precision("fp32_f16x2")
+    g = torch.Generator().manual_seed(19)
+    x, c = torch.randn(N, 560, T, generator=g), torch.randn(N, 560, T, generator=g)
+    ln = None if lens is None else torch.tensor(lens)
+    sd = cpu_sd(m)
+    m = m.to(dev)
+    kw = {} if ln is None else dict(in_lengths=ln.to(dev), out_lengths=ln.to(dev))
+    monkeypatch.setenv("DMEL_WAVENET_PRESPLIT", "1")
+    y1 = m(x.to(dev), condition=c.to(dev), **kw)
+    monkeypatch.setenv("DMEL_WAVENET_PRESPLIT", "0")
+    y0 = m(x.to(dev), condition=c.to(dev), **kw)
+    assert torch.equal(y1, y0), float((y1 - y0).abs().max())
+    if ln is None:
+        ref = ref_cpu.wavenet_forward(sd, "", x, L, condition=c)
+        assert rel_err(y1, ref) < TOL
+
+
 @pytest.mark.parametrize("levels,prebound", [([7, 5, 5], True), ([7, 5, 5], False), ([8, 6], True)])
 def test_quantizer_encode_decode(dev, levels, prebound):
     from dmel_codec_amd.models.modules.dowmsample_fsq import DownsampleFiniteScalarQuantize
@@ -391,11 +419,12 @@ def test_bigvgan_ampblock2_golden(dev, golden):
 def assert_close_to_truth(y, ref32, ref64, what=""):
     """Deep random-weight stacks amplify rounding noise: the fp32 oracle itself moves by 3-5e-5 relative when only
     its thread count (oneDNN blocking) changes.  So whole-network outputs are judged against the SAME oracle run in
-    float64: the kernel must be within 1e-4 of the truth or within 3x the fp32 oracle's own distance from it.  Every call puts its
+    float64: the kernel must be within 1e-4 of the truth or within 1.5x the fp32 oracle's own distance from it.  Every call puts its
     three numbers on record (gpurun_out/parity_report.txt -> profiles/): how much of the allowance is used is visible, not assumed."""
     e_gpu, e_ref, e_32 = rel_err(y, ref64), rel_err(ref32, ref64), rel_err(y, ref32)
     report(f"[truth] {what}: gpu-vs-fp64 {e_gpu:.2e}, oracle-fp32-vs-fp64 {e_ref:.2e}, gpu-vs-oracle-fp32 {e_32:.2e}")
-    assert e_gpu < max(TOL, 3.0 * e_ref), f"{what}: gpu-vs-fp64 {e_gpu:.2e}, oracle-fp32-vs-fp64 {e_ref:.2e}"
+    # round 3: every recorded case has e_gpu < e_ref (profiles/r03_parity_report.txt), so the relief factor went from 3 to 1.5
+    assert e_gpu < max(TOL, 1.5 * e_ref), f"{what}: gpu-vs-fp64 {e_gpu:.2e}, oracle-fp32-vs-fp64 {e_ref:.2e}"
     # (round 2 also allowed the two fp32 results 4x max(TOL, e_ref) of each other: that bound follows from the one above by the triangle
     # inequality -- e_32 <= e_gpu + e_ref -- and is no longer asserted separately; e_32 is on record instead)
 
@@ -608,6 +637,34 @@ def test_incremental_decode_with_state_carry(dev, pattern):
     assert sum(p[1].shape[-1] for p in parts) == T4 * 4 and all(p[0] is None for p in parts)
     mel_g = torch.cat([p[1] for p in codec.decode_stream(ids, flen, chunk_tokens=50, noise=noise, return_audios=False)], dim=-1)
     assert torch.equal(mel_g, mel)
+
+
+def test_streaming_decode_by_graph_replay_is_bit_identical(dev):
+    """VQGAN.decode_stream(use_graph=True): once the stream is in its steady state a push of `chunk_tokens` tokens is one HIP-graph replay
+    (quantiser window, every WaveNet block's new columns, vocoder window: ~250 launches -> 1).  The concatenated output must still be
+    BIT-identical to decode() of the whole sequence (lm_lit_modules.py:467-471 decodes once, at the end), most pushes must actually have
+    been replays, and an odd-sized last chunk + the flush fall back to the launch-by-launch path on the same state."""
+    codec = make_codec(710, n_mels=80, dmel_groups=8, encoder_layers=2).to(dev)
+    g = torch.Generator().manual_seed(91)
+    B, T4, chunk = 2, 333, 24
+    ids = torch.randint(0, 175, (B, 8, T4), generator=g, dtype=torch.int32).to(dev)
+    noise = torch.randn(B, codec.decoder.input_channels, T4 * 4, generator=g).to(dev)
+    flen = torch.full((B,), T4, device=dev)
+    wav_ref, mel_ref = codec.decode(ids, flen, return_audios=True, noise=noise)
+    for use_graph in (False, True):
+        dec = codec.streaming_decoder(B, None, True, graph_chunk_tokens=chunk if use_graph else None)
+        wavs, mels = [], []
+        for a0 in range(0, T4, chunk):
+            n = min(chunk, T4 - a0)
+            a, m = dec.push(ids[:, :, a0:a0 + n], noise=noise[:, :, a0 * 4:(a0 + n) * 4])
+            wavs.append(a); mels.append(m)
+        a, m = dec.finish()
+        wavs.append(a); mels.append(m)
+        wav, mel = torch.cat(wavs, dim=-1), torch.cat(mels, dim=-1)
+        assert wav.shape == wav_ref.shape and torch.equal(mel, mel_ref) and torch.equal(wav, wav_ref), use_graph
+        if use_graph:
+            report(f"[stream] graph replay: {dec.graph_replays} of {T4 // chunk} full chunks were graph replays")
+            assert dec.graph_replays >= T4 // chunk - 8
 
 
 def test_ragged_batch_with_empty_item(dev):

@@ -32,6 +32,40 @@ for chunk in (8, 32, 64, 128):
     el = time.perf_counter() - t0
     print(json.dumps({"mode": "state carry", "chunk_tokens": chunk, "first_audio_ms": round(first * 1e3, 2), "first_audio_after_tokens": first_tokens,
                       "audio_s": round(n / 24000, 2), "audio_sec_per_sec": round(n / 24000 / el, 1)}), flush=True)
+# the same stream with steady-state pushes replayed as ONE HIP graph each (StreamingDecoder(graph_chunk_tokens=...)), batch 1 and a batch of
+# independent streams (what "replicas" of BASELINE config 5 share one GPU as).  A longer stream (120 s) so that the one-time capture and the
+# start-up pushes do not dominate; the steady-state time per push is timed separately over the last pushes.
+T4L = 2813
+gl = torch.Generator().manual_seed(6)
+ids_long = torch.randint(0, 175, (1, 10, T4L), generator=gl, dtype=torch.int32).to(dev)
+for B in (1, 16):
+    ids_b = ids_long.expand(B, -1, -1).contiguous()
+    for chunk in (32, 64, 128):
+        for graph in (False, True):
+            for rep in range(2):                # first pass warms handles / workspaces
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                dec = codec.streaming_decoder(B, None, True, graph_chunk_tokens=chunk if graph else None)
+                n = 0
+                starts = list(range(0, T4L, chunk))
+                t_steady = None
+                for i, a0 in enumerate(starts):
+                    if i == len(starts) - 21:
+                        torch.cuda.synchronize()
+                        t_steady = time.perf_counter()
+                    a, m = dec.push(ids_b[:, :, a0:a0 + chunk])
+                    n += a.shape[-1]
+                    if i == len(starts) - 2:
+                        torch.cuda.synchronize()
+                        steady_ms = (time.perf_counter() - t_steady) * 1e3 / 20
+                a, m = dec.finish()
+                n += a.shape[-1]
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+            print(json.dumps({"mode": "state carry + graph replay" if graph else "state carry", "batch": B, "chunk_tokens": chunk,
+                              "graph_replays": dec.graph_replays, "pushes": len(starts), "steady_ms_per_push": round(steady_ms, 3),
+                              "steady_audio_sec_per_sec_all_streams": round(B * chunk * 4 * 256 / 24000 / (steady_ms * 1e-3), 1),
+                              "audio_s_per_stream": round(n / 24000, 2), "audio_sec_per_sec_all_streams": round(B * n / 24000 / el, 1)}), flush=True)
 for chunk in (32, 64, 128):
     codec.decode_chunked(ids, flen, chunk_tokens=chunk)
     torch.cuda.synchronize()
