@@ -375,6 +375,12 @@ typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 // shape gained (-4 .. +2 %), with or without a weight prefetch distance of 3 -- the x loads are not what the waves wait for.  Stays 0.
 #define DMEL_XTOP 0
 #endif
+#ifndef DMEL_BPF
+// 1: the B fragments of step s + 1 are read from LDS BEFORE the MFMAs of step s (two fragment register sets), whenever the next step
+// belongs to the same staged chunk.  A lone wave on its SIMD (the decoder WaveNet at 32 x 92 frames: 288 workgroups for 256 CUs) otherwise
+// meets the LDS latency at the top of every step with nothing else to issue.
+#define DMEL_BPF 0
+#endif
 #ifndef DMEL_KG2
 #define DMEL_KG2 2  // 8-channel groups staged per barrier by the fp16-split kernel when the convolution has taps
 #endif
@@ -643,6 +649,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   constexpr int kXLoads = NIT * (PS != 0 ? 2 : 8);                                          // x loads per thread and chunk
   constexpr int kWX = kWLoads + kXLoads < 63 ? kWLoads + kXLoads : 63;
   constexpr int kWaitWX = (kWX & 15) | (7 << 4) | (15 << 8) | ((kWX >> 4) << 14);           // ... that also leaves a chunk of x loads in flight
+#if DMEL_BPF
+  bf16x8 bfrag[2][NT][NP];
+  bool have_frag = false;
+#endif
   auto k_step = [&](auto R, int s) {
     constexpr int r = decltype(R)::value;
     uint4 (&use)[MT][NP] = wa[r % (PD + 1)];
@@ -671,12 +681,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     // would put a wait-free path into the CFG and with it a conservative vmcnt(0) in front of the MFMAs
     if (!(DMEL_EXP & 4)) load_w(wa[(r + PD) % (PD + 1)], min(s + PD, a.steps - 1));
     {
+#if DMEL_BPF
+      bf16x8 (&bcur)[NT][NP] = bfrag[r % 2];
+      bf16x8 (&bnxt)[NT][NP] = bfrag[(r + 1) % 2];
+      if (!have_frag) {
+        const uint4* xp = Xb + xbuf * (NP * PSZ) + ((c16 % SUB) * 2 + h) * XS + wave_n * (NT * 32) + l31 + tap * cur_dil;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) bcur[ni][p] = __builtin_bit_cast(bf16x8, xp[p * PSZ + ni * 32]);
+      }
+      have_frag = has_next && !newx;
+      if (have_frag) {      // next step reads the same staged chunk: its fragments travel while this step multiplies
+        const uint4* xq = Xb + xbuf * (NP * PSZ) + ((nc16 % SUB) * 2 + h) * XS + wave_n * (NT * 32) + l31 + ntap * cur_dil;
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+          for (int p = 0; p < NP; ++p) bnxt[ni][p] = __builtin_bit_cast(bf16x8, xq[p * PSZ + ni * 32]);
+      }
+#else
       const uint4* xp = Xb + xbuf * (NP * PSZ) + ((c16 % SUB) * 2 + h) * XS + wave_n * (NT * 32) + l31 + tap * cur_dil;
       bf16x8 bcur[NT][NP];
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
         for (int p = 0; p < NP; ++p) bcur[ni][p] = __builtin_bit_cast(bf16x8, xp[p * PSZ + ni * 32]);
+#endif
       if constexpr (NP == 2) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
@@ -725,8 +755,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     sg = nsg; c16 = nc16; tap = ntap;
   };
   // unrolled by the PD + 1 weight sets so that they rotate without register copies
-  constexpr int UNR = PD + 1;
-  static_assert(UNR <= 6, "k_step calls below cover an unroll of up to six");
+  // (DMEL_BPF: and by the two fragment sets -- the unroll is the least common multiple, so that both rotations are compile-time indices)
+  constexpr int UNR = DMEL_BPF ? ((PD + 1) % 2 ? 2 * (PD + 1) : PD + 1) : PD + 1;
+  static_assert(UNR <= 8, "k_step calls below cover an unroll of up to eight");
   for (int s = 0; s < a.steps; s += UNR) {
     k_step(std::integral_constant<int, 0>{}, s);
     if (s + 1 < a.steps) k_step(std::integral_constant<int, 1>{}, s + 1);
@@ -734,6 +765,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
     if (UNR > 3 && s + 3 < a.steps) k_step(std::integral_constant<int, 3 % UNR>{}, s + 3);
     if (UNR > 4 && s + 4 < a.steps) k_step(std::integral_constant<int, 4 % UNR>{}, s + 4);
     if (UNR > 5 && s + 5 < a.steps) k_step(std::integral_constant<int, 5 % UNR>{}, s + 5);
+    if (UNR > 6 && s + 6 < a.steps) k_step(std::integral_constant<int, 6 % UNR>{}, s + 6);
+    if (UNR > 7 && s + 7 < a.steps) k_step(std::integral_constant<int, 7 % UNR>{}, s + 7);
   }
   if constexpr (NP == 2) {
 #pragma unroll
