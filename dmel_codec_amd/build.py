@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdmel_hip.so")
-SOURCES = ["common.cpp", "stft_logmel.hip", "stft_bwd.hip", "conv_igemm.hip", "conv_snake.hip", "conv_bwd.hip", "train_ops.hip", "aa_snake.hip", "small_ops.hip", "wavenet_fused.hip", "modules.hip"]
+SOURCES = ["common.cpp", "stft_logmel.hip", "stft_bwd.hip", "conv_igemm.hip", "conv_pc.hip", "conv_snake.hip", "conv_bwd.hip", "train_ops.hip", "aa_snake.hip", "small_ops.hip", "wavenet_fused.hip", "modules.hip"]
 HEADERS = ["common.h", "conv.h", "conv_dev.h", "snake_dev.h", "ops.h", os.path.join("..", "..", "include", "dmel_hip.h")]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-x", "hip"]
 

@@ -975,6 +975,10 @@ int launch_split_planes(const float* x, void* planes, int64_t plane_units, const
 }
 
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
+  {  // producer / consumer kernel for the launches it was measured to win on (conv_pc.hip); DMEL_CONV_PC=0 is the A/B switch, read per call
+    const char* e = getenv("DMEL_CONV_PC");
+    if (!(e && e[0] == '0') && conv_pc_eligible(pc, r)) return launch_conv_pc(pc, r, stream);
+  }
   KArgs ka{};
   const PackDesc& d = pc.d;
   ka.nseg = d.nseg;

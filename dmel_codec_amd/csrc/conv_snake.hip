@@ -45,7 +45,9 @@ struct SnakeArgs {
 constexpr int kSegW = 122;    // output columns per producer item: 122 + 6 = 128 pairs of the 2x signal = two full passes of 64 lanes
 constexpr int kXRow = 136;    // floats per staged x row (kSegW + 12 = 134) and float2 per activated row (128 + the 6 idle lanes read ahead)
 
-template <int WM, int WN, int NT, int NPROD, int HALO>
+// ACT = false: the same workgroup without the activation -- the producers only stage x (load, scale, split, LDS), the consumers run the
+// same lean MFMA loop.  A plain convolution whose matrix waves carry no staging arithmetic (round-3 experiment against conv_bf16_kernel).
+template <int WM, int WN, int NT, int NPROD, int HALO, bool ACT = true>
 __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArgs a, SnakeArgs sa) {
   constexpr int NC = WM * WN;
   constexpr int BN = WN * NT * 32;
@@ -134,6 +136,69 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
   // (at most IPP).  Per chunk: (1) the x rows of all its items, fetched into registers one chunk ahead, go to private LDS rows;
   // (2) the loads of the next chunk are issued; (3) the items are computed one after the other (a run-time loop: one copy of the code).
   const int p = wave_u - NC;
+  if constexpr (!ACT) {
+    // plain staging: an item is a channel pair x up to 128 columns (two passes of 64 lanes); loads of the next chunk in flight while this one
+    // is converted
+    constexpr int SEG2 = 128, NS2 = (XS + SEG2 - 1) / SEG2, IP2 = (8 * NS2 + NPROD - 1) / NPROD;
+    const int T = (int)a.seg[0].Tin, Cin = a.seg[0].Cin;
+    const int wx = BN + (taps - 1) * dil;
+    const int tau0 = q0 - a.seg[0].pad_left;
+    const int nitems = 8 * ((wx + SEG2 - 1) / SEG2);
+    const float* xb = a.seg[0].x + (int64_t)b * a.seg[0].bstride;
+    const int cs = (int)a.seg[0].cstride;
+    float pre[IP2][2][2];
+    auto fetch2 = [&](int chunk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int r = 0; r < IP2; ++r) {
+        const int it = p + NPROD * r;
+        if (it >= nitems) break;
+        const int cp = it & 7, tb = tau0 + (it >> 3) * SEG2;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const float* xr = xb + (int64_t)min(chunk * 16 + 2 * cp + c, Cin - 1) * cs;
+#pragma unroll
+          for (int k = 0; k < 2; ++k) pre[r][c][k] = xr[min(max(tb + lane + 64 * k, 0), T - 1)];
+        }
+      }
+    };
+    fetch2(0);
+    for (int ck = 0; ck < nchunk; ++ck) {
+      uint4* dst = Xb + (ck & 1) * (2 * PSZ);
+      float cur[IP2][2][2];
+#pragma unroll
+      for (int r = 0; r < IP2; ++r)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int k = 0; k < 2; ++k) cur[r][c][k] = pre[r][c][k];
+      if (ck + 1 < nchunk) fetch2(ck + 1);
+#pragma unroll
+      for (int r = 0; r < IP2; ++r) {
+        const int it = p + NPROD * r;
+        if (it >= nitems) break;
+        const int cp = it & 7, j0 = (it >> 3) * SEG2, w = min(SEG2, wx - j0), tb = tau0 + j0;
+        const float sc0 = ck * 16 + 2 * cp < Cin ? kF16XScale : 0.f, sc1 = ck * 16 + 2 * cp + 1 < Cin ? kF16XScale : 0.f;
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(dst) + ((2 * cp) >> 3) * (XS * 4) + (((2 * cp) & 7) >> 1);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int o = lane + 64 * k, t = tb + o;
+          const bool ok = t >= 0 && t < T;
+          {
+#pragma clang fp contract(off)
+            const float v0 = (ok ? cur[r][0][k] : 0.f) * sc0, v1 = (ok ? cur[r][1][k] : 0.f) * sc1;
+            const f16x2 hi = __builtin_convertvector((f32x2){v0, v1}, f16x2);
+            const f16x2 lo = __builtin_convertvector((f32x2){(v0 - (float)hi[0]) * kF16LoScale, (v1 - (float)hi[1]) * kF16LoScale}, f16x2);
+            if (o < w) {
+              d32[(j0 + o) * 4] = __builtin_bit_cast(uint32_t, hi);
+              d32[PSZ * 4 + (j0 + o) * 4] = __builtin_bit_cast(uint32_t, lo);
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+    return;
+  }
   float* xsb = smem + 2 * 2 * PSZ * 4 + p * SCR;           // xs[IPP][2][kXRow]
   float2* vs0 = reinterpret_cast<float2*>(xsb + IPP * 2 * kXRow);
   float2* vs1 = vs0 + kXRow;
@@ -301,13 +366,13 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_snake_kernel(KArg
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------------------
-template <int WM, int WN, int NT, int NPROD, int HALO>
+template <int WM, int WN, int NT, int NPROD, int HALO, bool ACT>
 static int launch_cs(const KArgs& ka, const SnakeArgs& sa, int B, hipStream_t st) {
   constexpr int BN = WN * NT * 32, XS = BN + HALO;
   constexpr int IPP = (8 * ((XS + kSegW - 1) / kSegW) + NPROD - 1) / NPROD;
-  constexpr size_t lds = (size_t)2 * 2 * 2 * XS * 16 + (size_t)NPROD * ((IPP * 2 + 4) * kXRow) * 4;
+  constexpr size_t lds = (size_t)2 * 2 * 2 * XS * 16 + (ACT ? (size_t)NPROD * ((IPP * 2 + 4) * kXRow) * 4 : 0);
   static_assert(lds <= 160 * 1024, "fused tile exceeds the LDS of a CU");
-  auto kern = conv_snake_kernel<WM, WN, NT, NPROD, HALO>;
+  auto kern = conv_snake_kernel<WM, WN, NT, NPROD, HALO, ACT>;
   if (lds > 64 * 1024) {
     static int rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     DMEL_HIP((hipError_t)rc);
@@ -319,10 +384,10 @@ static int launch_cs(const KArgs& ka, const SnakeArgs& sa, int B, hipStream_t st
   return DMEL_OK;
 }
 
-template <int WM, int WN, int NT, int NPROD>
+template <int WM, int WN, int NT, int NPROD, bool ACT>
 static int launch_cs_h(const KArgs& ka, const SnakeArgs& sa, int B, int halo, hipStream_t st) {
-  if (halo <= 16) return launch_cs<WM, WN, NT, NPROD, 16>(ka, sa, B, st);
-  return launch_cs<WM, WN, NT, NPROD, 64>(ka, sa, B, st);
+  if (halo <= 16) return launch_cs<WM, WN, NT, NPROD, 16, ACT>(ka, sa, B, st);
+  return launch_cs<WM, WN, NT, NPROD, 64, ACT>(ka, sa, B, st);
 }
 
 bool conv_snake_eligible(const PackedConv& pc, const ConvRun& r) {
@@ -339,7 +404,7 @@ int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha
                       const float* down_taps_host, int logscale, hipStream_t stream) {
   DMEL_CHECK_ARG(conv_snake_eligible(pc, r), "conv_snake: this convolution cannot take the fused activation (plain 'same' convolution, "
                                              "fp16-split precision, no masks)");
-  DMEL_CHECK_ARG(r.seg[0].x && r.y && alpha && up_taps_host && down_taps_host && r.B > 0 && r.Tcols > 0, "conv_snake: NULL argument / bad shape");
+  DMEL_CHECK_ARG(r.seg[0].x && r.y && r.B > 0 && r.Tcols > 0 && (alpha == nullptr || (up_taps_host && down_taps_host)), "conv_snake: NULL argument / bad shape");
   const PackDesc& d = pc.d;
   const SegDesc& sd = d.seg[0];
   KArgs ka{};
@@ -359,7 +424,7 @@ int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha
   ka.mtiles = pc.Mpad / 32;
   SnakeArgs sa;
   sa.alpha = alpha; sa.beta = beta ? beta : alpha; sa.logscale = logscale;
-  for (int i = 0; i < 12; ++i) { sa.tu.f[i] = 2.f * up_taps_host[i]; sa.td.f[i] = down_taps_host[i]; }
+  for (int i = 0; i < 12; ++i) { sa.tu.f[i] = alpha ? 2.f * up_taps_host[i] : 0.f; sa.td.f[i] = alpha ? down_taps_host[i] : 0.f; }
   const int halo = (sd.taps - 1) * sd.dil;
   const double in_elems = (double)sd.Cin * (double)r.seg[0].Tin;
   const double out_elems = (double)d.C * (double)r.Tcols * (1.0 + (r.res ? 1.0 : 0.0) + (r.accumulate ? 1.0 : 0.0));
@@ -367,12 +432,26 @@ int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha
   const double alg_flops = 2.0 * r.B * (double)r.Tcols * (double)d.C * pc.k_real;
   ProfScope ps("conv_igemm", stream, alg_flops, alg_bytes, alg_flops * 3.0);
   const int mt = ka.mtiles;
+  if (alpha == nullptr) {
+    // plain convolution: EIGHT consumer waves in every configuration (two per SIMD hide each other's waits; with four the lean loop
+    // measured 0.55-0.75x of conv_bf16_kernel, with eight 1.10-1.19x) and four producers for the conversion
+    static const int cfg = [] { const char* e = getenv("DMEL_LEAN_CFG"); return e ? atoi(e) : 0; }();     // A/B: 1 = sixteen-wave workgroups
+    if (mt >= 5) return launch_cs_h<8, 1, 3, 4, false>(ka, sa, r.B, halo, stream);
+    if (cfg == 1) {      // 8 consumers of 32 x 64 + 8 producers, <= 128 registers, four waves per SIMD
+      if (mt >= 3) return launch_cs_h<4, 2, 2, 8, false>(ka, sa, r.B, halo, stream);
+      if (mt == 2) return launch_cs_h<2, 4, 2, 8, false>(ka, sa, r.B, halo, stream);
+      return launch_cs_h<1, 8, 2, 8, false>(ka, sa, r.B, halo, stream);
+    }
+    if (mt >= 3) return launch_cs_h<4, 2, 3, 4, false>(ka, sa, r.B, halo, stream);
+    if (mt == 2) return launch_cs_h<2, 4, 3, 4, false>(ka, sa, r.B, halo, stream);
+    return launch_cs_h<1, 8, 3, 4, false>(ka, sa, r.B, halo, stream);
+  }
   // one 32-row strip per consumer wave; fewer rows -> the consumers spread over the columns instead (BN = 96 WN), so that every
   // configuration has four (eight) matrix waves, one (two) per SIMD, next to eight (four) producers
-  if (mt >= 5) return launch_cs_h<8, 1, 3, 4>(ka, sa, r.B, halo, stream);
-  if (mt >= 3) return launch_cs_h<4, 1, 3, 8>(ka, sa, r.B, halo, stream);
-  if (mt == 2) return launch_cs_h<2, 2, 3, 8>(ka, sa, r.B, halo, stream);
-  return launch_cs_h<1, 3, 3, 8>(ka, sa, r.B, halo, stream);      // 288 columns: three full segments for the eight producers
+  if (mt >= 5) return launch_cs_h<8, 1, 3, 4, true>(ka, sa, r.B, halo, stream);
+  if (mt >= 3) return launch_cs_h<4, 1, 3, 8, true>(ka, sa, r.B, halo, stream);
+  if (mt == 2) return launch_cs_h<2, 2, 3, 8, true>(ka, sa, r.B, halo, stream);
+  return launch_cs_h<1, 3, 3, 8, true>(ka, sa, r.B, halo, stream);      // 288 columns: three full segments for the eight producers
 }
 
 }  // namespace dmel
@@ -382,7 +461,7 @@ extern "C" int dmel_conv_snake_forward(const dmel_conv* c, const float* x, const
                                        const float* beta, const float* up_filter12_host, const float* down_filter12_host, int logscale,
                                        int B, int64_t T, void* stream) {
   using namespace dmel;
-  DMEL_CHECK_ARG(c && x && y && alpha && up_filter12_host && down_filter12_host, "conv_snake_forward: NULL argument");
+  DMEL_CHECK_ARG(c && x && y && (alpha == nullptr || (up_filter12_host && down_filter12_host)), "conv_snake_forward: NULL argument");
   ConvRun r;
   r.seg[0].x = x; r.seg[0].bstride = (int64_t)c->Cin * T; r.seg[0].cstride = T; r.seg[0].Tin = T;
   r.B = B; r.Tcols = T; r.y = y; r.y_bs = (int64_t)c->Cout * T; r.y_cs = T; r.Tout = T;

@@ -61,6 +61,12 @@ bool conv_snake_eligible(const PackedConv& pc, const ConvRun& r);
 int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha, const float* beta, const float* up_taps_host,
                       const float* down_taps_host, int logscale, hipStream_t stream);
 
+// Producer / consumer form of the fp16-split convolution (conv_pc.hip): eight consumer waves that only run the MFMA loop + four producer
+// waves that stage x.  launch_conv hands eligible launches (>= 5 row tiles, fp16-split precision, no masks / strides / phases) to it
+// unless DMEL_CONV_PC=0.  Bit-identical to conv_bf16_kernel<NP = 2>.
+bool conv_pc_eligible(const PackedConv& pc, const ConvRun& r);
+int launch_conv_pc(const PackedConv& pc, const ConvRun& r, hipStream_t stream);
+
 // ---- training path (train_ops.hip, conv_bwd.hip) --------------------------------------------------------------
 int launch_gate_fwd(const float* pre, float* z, int N, int C, int64_t T, hipStream_t s);
 int launch_gate_bwd(const float* dz, const float* pre, float* dpre, int N, int C, int64_t T, hipStream_t s);

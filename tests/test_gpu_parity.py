@@ -253,6 +253,65 @@ def near_tie_report(ids_gpu, ids_ref, pre_ref, eps=2e-4):
     return int(diff.sum()), int((diff & ~tie).sum()), int(tie.sum())
 
 
+def test_producer_consumer_convolution_is_bit_identical(dev, monkeypatch):
+    """conv_pc.hip (eight consumer waves that only run the MFMA loop + four producer waves that stage x) serves the fp16-split launches of
+    >= 5 row tiles -- the decoder WaveNet's gate (two segments, sigmoid * tanh epilogue) and residual / skip convolutions, the 256-channel
+    vocoder stage -- unless DMEL_CONV_PC=0.  Same operand bits, K order and epilogue: torch.equal against conv_bf16_kernel on single
+    convolutions (ragged channel counts, both halos, residual), on the conditioned WaveNet (with masks) and on a whole vocoder."""
+    from dmel_codec_amd import _lib
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    L = _lib.lib()
+
+    def both(fn):
+        monkeypatch.setenv("DMEL_CONV_PC", "1")
+        a = fn()
+        monkeypatch.setenv("DMEL_CONV_PC", "0")
+        b = fn()
+        return a, b
+
+    for (Co, Ci, k, dil, T, B) in ((256, 256, 3, 1, 300, 2), (256, 256, 11, 5, 97, 1), (200, 168, 7, 3, 96, 2), (512, 80, 7, 1, 92, 3), (1120, 560, 3, 8, 92, 2)):
+        torch.manual_seed(Co + k)
+        w = torch.randn(Co, Ci, k) / math.sqrt(Ci * k)
+        bb = torch.randn(Co) * 0.1
+        x = torch.randn(B, Ci, T).to(dev)
+        h = C.c_void_p()
+        _lib.check(L.dmel_conv_create(C.byref(h), w.data_ptr(), bb.data_ptr(), Co, Ci, k, dil))
+        _lib.check(L.dmel_conv_set_precision(h, 3))
+
+        def run():
+            y = torch.full((B, Co, T), float("nan"), device=dev)
+            _lib.check(L.dmel_conv_forward(h, x.data_ptr(), y.data_ptr(), B, T, _lib.stream_ptr()))
+            torch.cuda.synchronize()
+            return y
+        y1, y0 = both(run)
+        assert torch.equal(y1, y0), (Co, Ci, k, dil, T, float((y1 - y0).abs().max()))
+        assert rel_err(y1, F.conv1d(x.cpu().double(), w.double(), bb.double(), dilation=dil, padding=dil * (k - 1) // 2)) < 2e-5
+        L.dmel_conv_destroy(h)
+    # the conditioned decoder WaveNet: gate (x k3 dilated + condition 1x1, GATE epilogue) and residual / skip (1x1, RESSKIP epilogue)
+    torch.manual_seed(23)
+    m = WaveNet(input_channels=560, output_channels=80, residual_channels=560, residual_layers=5, dilation_cycle=4, condition_channels=560)
+    randomise(m, 24)
+    m.set_precision("fp32_f16x2")
+    m = m.to(dev)
+    g = torch.Generator().manual_seed(25)
+    for (N, T, lens) in ((3, 92, None), (2, 200, [200, 77])):
+        x, c = torch.randn(N, 560, T, generator=g).to(dev), torch.randn(N, 560, T, generator=g).to(dev)
+        kw = {} if lens is None else dict(in_lengths=torch.tensor(lens).to(dev), out_lengths=torch.tensor(lens).to(dev))
+        y1, y0 = both(lambda: m(x, condition=c, **kw))
+        assert torch.equal(y1, y0), (N, T, float((y1 - y0).abs().max()))
+    # a vocoder with a 256-channel first stage
+    from dmel_codec_amd.models.modules.bigvgan.bigvgan import BigVGAN
+    from dmel_codec_amd.configs import bigvgan_h
+    hcfg = bigvgan_h("base_24k_100band", num_mels=80)
+    torch.manual_seed(26)
+    v = BigVGAN(hcfg)
+    randomise(v, 27, scale=0.7)
+    v = v.to(dev)
+    mel = torch.randn(2, 80, 20, generator=g).to(dev)
+    y1, y0 = both(lambda: v(mel))
+    assert torch.equal(y1, y0)
+
+
 @pytest.mark.parametrize("N,T,L,lens", [(3, 92, 4, None), (2, 300, 5, None), (4, 92, 3, [92, 50, 0, 91]), (1, 937, 2, None)])
 def test_decoder_wavenet_with_presplit_operands_is_bit_identical(dev, monkeypatch, N, T, L, lens):
     """The conditioned 560-channel decoder WaveNet at the fp16-split precision reads every convolution input as pre-split fp16 planes

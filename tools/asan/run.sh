@@ -8,7 +8,7 @@ mkdir -p "$OUT"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="-O1 -g -fsanitize=address -fno-omit-frame-pointer -fPIC -std=c++17"
 objs=""
-for f in common.cpp stft_logmel.hip stft_bwd.hip conv_igemm.hip conv_snake.hip conv_bwd.hip train_ops.hip aa_snake.hip small_ops.hip wavenet_fused.hip modules.hip; do
+for f in common.cpp stft_logmel.hip stft_bwd.hip conv_igemm.hip conv_pc.hip conv_snake.hip conv_bwd.hip train_ops.hip aa_snake.hip small_ops.hip wavenet_fused.hip modules.hip; do
   o="$OUT/${f%.*}.o"
   $HIPCC $FLAGS --offload-host-only -x hip -c "$ROOT/dmel_codec_amd/csrc/$f" -o "$o"
   objs="$objs $o"

@@ -45,6 +45,7 @@ def main():
         u = torch.empty_like(x)
         y = torch.empty_like(x)
         y2 = torch.empty_like(x)
+        y3 = torch.empty_like(x)
         al, be = (torch.randn(Cc) * 0.3).to(dev), (torch.randn(Cc) * 0.3).to(dev)
         st = _lib.stream_ptr()
 
@@ -57,6 +58,9 @@ def main():
         def fused():
             _lib.check(L.dmel_conv_snake_forward(h, x.data_ptr(), None, y2.data_ptr(), al.data_ptr(), be.data_ptr(), taps.data_ptr(), taps.data_ptr(), 1, B, T, st))
 
+        def lean():      # the producer / consumer workgroup WITHOUT the activation: a plain convolution of u
+            _lib.check(L.dmel_conv_snake_forward(h, u.data_ptr(), None, y3.data_ptr(), None, None, None, None, 1, B, T, st))
+
         def timed(fn):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -66,18 +70,18 @@ def main():
             torch.cuda.synchronize()
             return e0.elapsed_time(e1) / args.iters * 1e3
 
-        for fn in (snake, conv, fused):
+        for fn in (snake, conv, fused, lean):
             fn()
-        best = [1e30, 1e30, 1e30]
+        best = [1e30, 1e30, 1e30, 1e30]
         for _ in range(args.rounds):
-            for i, fn in enumerate((snake, conv, fused)):
+            for i, fn in enumerate((snake, conv, fused, lean)):
                 best[i] = min(best[i], timed(fn))
-        same = bool(torch.equal(y, y2))
+        same = bool(torch.equal(y, y2)) and bool(torch.equal(y, y3))
         fl = 2.0 * B * T * Cc * Cc * k
         for i in range(3):
             tot[i] += best[i]
         print(f"{name:10s} C={Cc:4d} k={k:2d} d={dil} T={T:6d}x{B}: snake {best[0]:7.1f} us + conv {best[1]:7.1f} us = {best[0] + best[1]:7.1f} | fused {best[2]:7.1f} us "
-              f"({fl / best[2] / 1e6:6.1f} TF/s, x{(best[0] + best[1]) / best[2]:.2f}) bit-identical {same}", flush=True)
+              f"({fl / best[2] / 1e6:6.1f} TF/s, x{(best[0] + best[1]) / best[2]:.2f}) | lean conv {best[3]:7.1f} us (x{best[1] / best[3]:.2f} of conv) bit-identical {same}", flush=True)
         L.dmel_conv_destroy(h)
     print(f"sum: snake {tot[0]:.0f} + conv {tot[1]:.0f} = {tot[0] + tot[1]:.0f} us, fused {tot[2]:.0f} us")
 
