@@ -19,6 +19,15 @@
 #include <cstdlib>
 #include <type_traits>
 
+#ifndef DMEL_PC_ASMW
+#define DMEL_PC_ASMW 0       // 1: weight stream of the consumers from inline assembly with hand-placed waits.  Removes the compiler's
+                            // vmcnt(0) in front of one step in three (checked in the ISA), bit-identical -- and measured within +-3 % of the
+                            // compiler-visible loads (profiles/r03_conv_experiments.txt): the weight latency is not the limiter.  Stays 0.
+#endif
+#ifndef DMEL_PC_SCHED
+#define DMEL_PC_SCHED 0      // 1: all six fragment reads issued before the first MFMA of a step (measured 3-8 % SLOWER than the compiler's interleave)
+#endif
+
 namespace dmel {
 
 typedef _Float16 pc_f16x8 __attribute__((ext_vector_type(8)));
@@ -53,15 +62,30 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_pc_kernel(KArgs a
     const int tile = min(mblk * WM + wave_m, a.mtiles - 1);
     const char* wT = reinterpret_cast<const char*>(a.w32h) + (size_t)tile * steps * 2048;
     const uint32_t lane16 = lane * 16;
+    // The consumer's only vector-memory traffic inside the K loop is this weight stream, and it is issued from inline assembly so that the
+    // compiler does not see it: hipcc's own s_waitcnt insertion is static, and at the head of the unrolled loop it merged the paths into
+    // a vmcnt(0) in front of one step in three -- a full L2 round trip for weights that are not needed until the NEXT step (the ISA of
+    // the builtin-load version: profiles/r03_pmc_conv.txt).  Ordering is by the explicit s_waitcnt vmcnt(2) at the end of every step
+    // (vmcnt retires in order: all but the two loads of step s + 2 have landed) followed by a scheduling barrier, so that no MFMA of the
+    // next step is hoisted above the wait (cdna_hip_programming.md, section 5.7 and rule 18); the loop's tail prefetches are drained by
+    // a vmcnt(0) before the registers are handed to the epilogue.
     auto load_w = [&](uint4 (&dst)[2], int step) __attribute__((always_inline)) {
-      const char* sp = wT + (size_t)step * 2048;
-      dst[0] = *reinterpret_cast<const uint4*>(sp + lane16);
-      dst[1] = *reinterpret_cast<const uint4*>(sp + 1024 + lane16);
+      const char* sp = wT + (size_t)step * 2048 + lane16;
+#if DMEL_PC_ASMW
+      asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:1024" : "=&v"(dst[0]), "=&v"(dst[1]) : "v"(sp) : "memory");
+#else
+      dst[0] = *reinterpret_cast<const uint4*>(sp);
+      dst[1] = *reinterpret_cast<const uint4*>(sp + 1024);
+#endif
     };
     constexpr int PD = 2;
     uint4 wa[PD + 1][2];
     load_w(wa[0], 0);
     load_w(wa[1], min(1, steps - 1));
+#if DMEL_PC_ASMW
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // simplest correct start: both sets landed before the loop (once per workgroup)
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     __syncthreads();                                      // chunk 0 is staged
     int tap = 0, xbuf = 0, ckl = 0, taps = a.seg[0].taps, dil = a.seg[0].dil, nch = nch0;
     constexpr int kWaitW = (2 & 15) | (7 << 4) | (15 << 8);      // s_waitcnt vmcnt(2): the weights of the next step have landed
@@ -77,6 +101,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_pc_kernel(KArgs a
         bl[ni] = __builtin_bit_cast(pc_f16x8, xp[PSZ + ni * 32]);
       }
       const pc_f16x8 ah = __builtin_bit_cast(pc_f16x8, use[0]), al = __builtin_bit_cast(pc_f16x8, use[1]);
+#if DMEL_PC_SCHED
+      // all six fragment reads (and the weight prefetch) are ISSUED before the first MFMA: left alone the compiler reads one fragment
+      // into one register quad, waits, multiplies, and re-uses the quad for the next read -- five exposed LDS round trips per step
+      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int ni = 0; ni < NT; ++ni) {
         acl[ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[ni], acl[ni], 0, 0, 0);
@@ -84,6 +113,9 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_pc_kernel(KArgs a
         acc[0][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[ni], acc[0][ni], 0, 0, 0);
       }
       __builtin_amdgcn_s_waitcnt(kWaitW);
+#if DMEL_PC_ASMW
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       if (++tap == taps) {
         tap = 0;
         ++ckl;
@@ -101,6 +133,11 @@ __global__ __launch_bounds__(64 * (WM * WN + NPROD)) void conv_pc_kernel(KArgs a
       if (s + 1 < steps) k_step(std::integral_constant<int, 1>{}, s + 1);
       if (s + 2 < steps) k_step(std::integral_constant<int, 2>{}, s + 2);
     }
+#if DMEL_PC_ASMW
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the tail's redundant prefetches: nothing may still be landing in registers the epilogue re-uses
+    __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
     for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
@@ -206,6 +243,8 @@ bool conv_pc_eligible(const PackedConv& pc, const ConvRun& r) {
     halo = std::max(halo, (sd.taps - 1) * sd.dil);
   }
   if (halo > 64 || (halo > 16 && d.mode != EPI_LINEAR)) return false;       // the paired modes are built with the 16-column halo only
+  if (halo == 0) return false;      // pointwise convolutions: a staged chunk is ONE K step here (a barrier per step); conv_bf16_kernel stages 32
+                                    // channels per barrier for them and stays ahead (wn_dec_1x1: 43 vs 46 us)
   return pc.Mpad / 32 >= 5;                                                   // eight strips of 32 rows per workgroup: the layout that gains
 }
 
