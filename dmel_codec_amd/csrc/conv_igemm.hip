@@ -648,7 +648,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   constexpr int kWaitW = (kWLoads & 15) | (7 << 4) | (15 << 8) | ((kWLoads >> 4) << 14);   // s_waitcnt vmcnt(kWLoads)
   constexpr int kXLoads = NIT * (PS != 0 ? 2 : 8);                                          // x loads per thread and chunk
   constexpr int kWX = kWLoads + kXLoads < 63 ? kWLoads + kXLoads : 63;
-  constexpr int kWaitWX = (kWX & 15) | (7 << 4) | (15 << 8) | ((kWX >> 4) << 14);           // ... that also leaves a chunk of x loads in flight
+  [[maybe_unused]] constexpr int kWaitWX = (kWX & 15) | (7 << 4) | (15 << 8) | ((kWX >> 4) << 14);           // ... that also leaves a chunk of x loads in flight
 #if DMEL_BPF
   bf16x8 bfrag[2][NT][NP];
   bool have_frag = false;
@@ -974,10 +974,40 @@ int launch_split_planes(const float* x, void* planes, int64_t plane_units, const
   return DMEL_OK;
 }
 
+// Debug range check of the fp16 split's documented domain (include/dmel_hip.h: activations are staged x 2^-6, so |x| must stay below
+// 2^6 * 65504 = 4.19e6; beyond that the first piece overflows to inf).  DMEL_DEBUG_F16_RANGE=1: reduce max |x| of every contiguous
+// input of such a launch, synchronise, and fail the launch LOUDLY if it is outside the domain.  Off by default (it serialises).
+static int check_f16_range(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
+  static const int range_check = [] { const char* e = getenv("DMEL_DEBUG_F16_RANGE"); return e ? atoi(e) : 0; }();
+  if (!range_check) return DMEL_OK;
+  const PackDesc& d = pc.d;
+  for (int s = 0; s < d.nseg; ++s) {
+    const SegRun& sr = r.seg[s];
+    if (sr.in_absmax || sr.cstride != sr.Tin || sr.bstride != (int64_t)d.seg[s].Cin * sr.cstride) continue;     // scaled by its own maximum / a view
+    const uint32_t* slot = nullptr;
+    DMEL_TRY(launch_absmax(sr.x, (int64_t)r.B * sr.bstride, stream, &slot));
+    uint32_t bits = 0;
+    DMEL_HIP(hipMemcpyAsync(&bits, slot, sizeof(bits), hipMemcpyDeviceToHost, stream));
+    DMEL_HIP(hipStreamSynchronize(stream));
+    float mx;
+    std::memcpy(&mx, &bits, sizeof(mx));
+    if (!(mx * sr.in_scale < kF16WScale * 65504.f)) {
+      set_error("conv (fp16 split): max |x| = %g of input segment %d is outside the documented domain |x| < %g "
+                "(DMEL_PRECISION_FP32_F16X2; use DMEL_PRECISION_FP32_BF16X3 for such tensors)", (double)mx * sr.in_scale, s,
+                (double)(kF16WScale * 65504.f));
+      return DMEL_EINVAL;
+    }
+  }
+  return DMEL_OK;
+}
+
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   {  // producer / consumer kernel for the launches it was measured to win on (conv_pc.hip); DMEL_CONV_PC=0 is the A/B switch, read per call
     const char* e = getenv("DMEL_CONV_PC");
-    if (!(e && e[0] == '0') && conv_pc_eligible(pc, r)) return launch_conv_pc(pc, r, stream);
+    if (!(e && e[0] == '0') && conv_pc_eligible(pc, r)) {
+      DMEL_TRY(check_f16_range(pc, r, stream));
+      return launch_conv_pc(pc, r, stream);
+    }
   }
   KArgs ka{};
   const PackDesc& d = pc.d;
@@ -1055,29 +1085,7 @@ int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
     return d.mode == EPI_GATE ? launch_presplit<EPI_GATE>(ka, r.B, r.Tcols, stream) : launch_presplit<EPI_RESSKIP>(ka, r.B, r.Tcols, stream);
   }
   if (r.precision == DMEL_PRECISION_FP32_F16X2 && !native_fp32) {
-    // Debug range check of the fp16 split's documented domain (include/dmel_hip.h: activations are staged x 2^-6, so |x| must stay below
-    // 2^6 * 65504 = 4.19e6; beyond that the first piece overflows to inf).  DMEL_DEBUG_F16_RANGE=1: reduce max |x| of every contiguous
-    // input of such a launch, synchronise, and fail the launch LOUDLY if it is outside the domain.  Off by default (it serialises).
-    static const int range_check = [] { const char* e = getenv("DMEL_DEBUG_F16_RANGE"); return e ? atoi(e) : 0; }();
-    if (range_check) {
-      for (int s = 0; s < d.nseg; ++s) {
-        const SegRun& sr = r.seg[s];
-        if (sr.in_absmax || sr.cstride != sr.Tin || sr.bstride != (int64_t)d.seg[s].Cin * sr.cstride) continue;     // scaled by its own maximum / a view
-        const uint32_t* slot = nullptr;
-        DMEL_TRY(launch_absmax(sr.x, (int64_t)r.B * sr.bstride, stream, &slot));
-        uint32_t bits = 0;
-        DMEL_HIP(hipMemcpyAsync(&bits, slot, sizeof(bits), hipMemcpyDeviceToHost, stream));
-        DMEL_HIP(hipStreamSynchronize(stream));
-        float mx;
-        std::memcpy(&mx, &bits, sizeof(mx));
-        if (!(mx * sr.in_scale < kF16WScale * 65504.f)) {
-          set_error("conv (fp16 split): max |x| = %g of input segment %d is outside the documented domain |x| < %g "
-                    "(DMEL_PRECISION_FP32_F16X2; use DMEL_PRECISION_FP32_BF16X3 for such tensors)", (double)mx * sr.in_scale, s,
-                    (double)(kF16WScale * 65504.f));
-          return DMEL_EINVAL;
-        }
-      }
-    }
+    DMEL_TRY(check_f16_range(pc, r, stream));
     return launch_bf16_any<2>(ka, d.mode, r.B, r.Tcols, stream);
   }
   if ((r.precision == DMEL_PRECISION_FP32 || r.precision == DMEL_PRECISION_FP32_BF16X3 || r.precision == DMEL_PRECISION_FP32_F16X2) && !native_fp32)
