@@ -26,7 +26,7 @@ def main():
     fetch_csv, write_csv, out = sys.argv[1:4]
     ft, fn = per_kernel(fetch_csv, "FETCH_SIZE")
     wt, wn = per_kernel(write_csv, "WRITE_SIZE")
-    fam = lambda k: "conv_bf16_kernel" in k or "conv_igemm_kernel" in k or "conv_direct_kernel" in k or "wavenet_fused_kernel" in k
+    fam = lambda k: "conv_bf16_kernel" in k or "conv_pc_kernel" in k or "conv_snake_kernel" in k or "conv_igemm_kernel" in k or "conv_direct_kernel" in k or "wavenet_fused_kernel" in k
     launches = sum(v for k, v in fn.items() if fam(k))
     fetch_kb = sum(v for k, v in ft.items() if fam(k))
     write_kb = sum(v for k, v in wt.items() if fam(k))
@@ -42,7 +42,7 @@ def main():
            "algorithmic_bytes_per_launch": None,
            "kernel_source_hash": __import__("bench").kernel_source_hash(),     # bench.py flags the figure as stale when the kernels change
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (two passes) over `bench.py --steps 2 --warmup 1 --cpu-budget 0 "
-                     "--median-steps 0 --streams 1`; conv family = conv_bf16_kernel<...> + wavenet_fused_kernel; FETCH_SIZE doubled "
+                     "--median-steps 0 --streams 1`; conv family = conv_bf16_kernel<...> + conv_pc_kernel<...> + wavenet_fused_kernel; FETCH_SIZE doubled "
                      "(gfx950 reports half of a wide coalesced read), WRITE_SIZE exact, KB -> bytes; profiles/r03_pmc_*.csv",
            "top_kernels": table}
     with open(out, "w") as f:
