@@ -76,6 +76,34 @@ DevBuf* thread_scratch(int which) {
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
   return &bufs[{dev, which}];
 }
+namespace {
+struct ClearedState { const char* lo = nullptr; const char* hi = nullptr; };
+ClearedState& cleared_state() {
+  static thread_local ClearedState s;
+  return s;
+}
+}  // namespace
+ClearedRange::ClearedRange(void* p, size_t bytes, hipStream_t s) : lo((const char*)p), hi((const char*)p + bytes), err(DMEL_OK) {
+  ClearedState& st = cleared_state();
+  prev_lo = st.lo; prev_hi = st.hi;
+  if (hipMemsetAsync(p, 0, bytes, s) != hipSuccess) {
+    set_error("gradient buffer: hipMemsetAsync of %zu bytes failed", bytes);
+    err = DMEL_EINVAL;
+    lo = hi = nullptr;
+  }
+  st.lo = lo; st.hi = hi;
+}
+ClearedRange::~ClearedRange() {
+  ClearedState& st = cleared_state();
+  st.lo = prev_lo; st.hi = prev_hi;
+}
+int zero_unless_cleared(void* p, size_t bytes, hipStream_t s) {
+  const ClearedState& st = cleared_state();
+  const char* c = (const char*)p;
+  if (st.lo && c >= st.lo && c + bytes <= st.hi) return DMEL_OK;
+  DMEL_HIP(hipMemsetAsync(p, 0, bytes, s));
+  return DMEL_OK;
+}
 int& train_precision_override() {
   static thread_local int v = -1;
   return v;

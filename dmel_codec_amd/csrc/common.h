@@ -117,6 +117,18 @@ struct DevBuf {
 // gets one buffer per device instead of a pointer into another GPU's memory).
 DevBuf* thread_scratch(int which);      // which: 0 absmax ring, 1 weight-gradient partial tiles, 2 folded discriminator weights
 
+// A backward pass clears its whole flat gradient buffer with ONE memset and declares the range here; launches inside it that would clear
+// their own slot first (weight / bias gradients that accumulate with atomics) ask zero_unless_cleared and skip theirs -- round 2 issued
+// ~480 memsets per training step that way.  Per thread, nested scopes restore the outer range.
+struct ClearedRange {
+  ClearedRange(void* p, size_t bytes, hipStream_t s);      // error(): result of the memset
+  ~ClearedRange();
+  int error() const { return err; }
+  const char *lo, *hi, *prev_lo, *prev_hi;
+  int err;
+};
+int zero_unless_cleared(void* p, size_t bytes, hipStream_t s);
+
 // Per-family launch timing (bench.py's roofline leg): hipEvents on the launch stream.
 struct ProfScope {
   // issue_flops: matrix-core flops actually issued for `flops` algorithmic ones (x6 for the bf16 split, x3 for the fp16 split, ...)

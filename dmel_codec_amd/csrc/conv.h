@@ -56,6 +56,15 @@ struct RepackSrc {
   int bias_mod = 0;          // > 0: the bias of source row sr is b0[sr % bias_mod] (one bias per output channel, shared by the phases)
 };
 int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t stream);
+// While a RepackBatch of this thread is alive, launch_repack only records its job; flush() sends all of them as ONE launch (a refresh
+// of a module is 2-120 convolutions: one launch instead of one each).  Nested batches join the outermost one.
+struct RepackBatch {
+  explicit RepackBatch(hipStream_t s);
+  ~RepackBatch();
+  int flush();
+  hipStream_t stream;
+  bool owner;
+};
 
 // get_w(seg, src_row, ci, tap) returns the source weight; get_b(src_row) the bias (0 if none).
 // Source row numbering: LINEAR: phase*C + co ; paired: kind*C + c.

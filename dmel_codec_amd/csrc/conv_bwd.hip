@@ -736,7 +736,7 @@ __global__ __launch_bounds__(256) void conv_bgrad_kernel(const float* __restrict
 static int launch_bgrad(const float* dy, float* db, int Cout, int B, int T, hipStream_t st) {
   const int total = B * ((T + kBgPiece - 1) / kBgPiece);
   const int splits = std::max(1, std::min(total, 2048 / std::max(1, Cout)));
-  if (splits > 1) DMEL_HIP(hipMemsetAsync(db, 0, (size_t)Cout * sizeof(float), st));
+  if (splits > 1) DMEL_TRY(zero_unless_cleared(db, (size_t)Cout * sizeof(float), st));
   hipLaunchKernelGGL(conv_bgrad_kernel, dim3((unsigned)Cout, (unsigned)splits), dim3(256), 0, st, dy, db, Cout, B, T);
   DMEL_HIP(hipGetLastError());
   return DMEL_OK;
@@ -751,7 +751,7 @@ int launch_conv_wgrad(const float* x, const float* dy, float* dw, float* db, int
   a.Cout = Cout; a.Cin = Cin; a.taps = taps; a.dil = dil; a.pad = dil * (taps - 1) / 2; a.B = B; a.T = (int)T;
   a.xstride = 1; a.xoff = 0; a.Tx = (int)T; a.taps_out = taps; a.tap_out = 0;
   a.dy_absmax = nullptr; a.partial = nullptr;
-  DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)Cout * Cin * taps * sizeof(float), st));
+  DMEL_TRY(zero_unless_cleared(dw, (size_t)Cout * Cin * taps * sizeof(float), st));
   {
     ProfScope ps("conv_wgrad", st, 2.0 * B * (double)T * Cout * Cin * taps, 0.0);
     DMEL_TRY(launch_wgrad_any(a, st));

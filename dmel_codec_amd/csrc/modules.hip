@@ -656,6 +656,7 @@ extern "C" int dmel_wavenet_refresh(dmel_wavenet* m, int n, const char* const* k
     *out = it->second;
     return DMEL_OK;
   };
+  RepackBatch batch((hipStream_t)stream);      // all convolutions of the network in one launch
   for (auto& r : m->recipes) {
     RepackSrc src;
     for (int sgi = 0; sgi < 2; ++sgi) {
@@ -666,7 +667,7 @@ extern "C" int dmel_wavenet_refresh(dmel_wavenet* m, int n, const char* const* k
     DMEL_TRY(find(r.b1, &src.b1));
     DMEL_TRY(launch_repack(*r.pc, src, (hipStream_t)stream));
   }
-  return DMEL_OK;
+  return batch.flush();
 }
 
 extern "C" size_t dmel_wavenet_train_workspace_bytes(const dmel_wavenet* m, int N, int64_t T) {
@@ -754,6 +755,8 @@ extern "C" int dmel_wavenet_backward_hooked(const dmel_wavenet* m, const float* 
   hipStream_t st = (hipStream_t)stream;
   const int C = m->C, Cc = m->Ccond, prec = train_precision(m);
   const size_t n = p.n;
+  ClearedRange cleared(grads, (size_t)m->grad_floats * sizeof(float), st);      // one memset for the ~120 gradient tensors of the network
+  DMEL_TRY(cleared.error());
   auto G = [&](const std::string& key) -> float* {
     for (const auto& s : m->slots)
       if (s.key == key) return grads + s.offset;
@@ -1337,6 +1340,7 @@ extern "C" int dmel_quantizer_refresh(dmel_quantizer* q, int n, const char* cons
     return it->second;
   };
   hipStream_t st = (hipStream_t)stream;
+  RepackBatch batch(st);
   const int C = q->Cg, G = q->G, D = q->D;
   auto copy = [&](DevBuf& dst, const float* src, size_t count) -> int {
     if (!src) return DMEL_EMISSING;
@@ -1401,7 +1405,7 @@ extern "C" int dmel_quantizer_refresh(dmel_quantizer* q, int n, const char* cons
     DMEL_HIP(hipMemcpyAsync(q->w_out.as<float>() + (size_t)g * C * D, o, (size_t)C * D * sizeof(float), hipMemcpyDeviceToDevice, st));
     DMEL_HIP(hipMemcpyAsync(q->b_out.as<float>() + (size_t)g * C, ob, (size_t)C * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
-  return DMEL_OK;
+  return batch.flush();
 }
 
 // ---- quantiser training path: DownsampleFiniteScalarQuantize.forward (dowmsample_fsq.py:86-122) and its backward ----------
@@ -1525,6 +1529,8 @@ extern "C" int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, 
   hipStream_t st = (hipStream_t)stream;
   const int N = B * q->G, C = q->Cg;
   const size_t NC = (size_t)N * C;
+  ClearedRange cleared(grads, (size_t)q->grad_floats * sizeof(float), st);
+  DMEL_TRY(cleared.error());
   const int64_t Tfull = p.up[q->nf - 1].Tout, diff = T - Tfull, left = diff / 2;
   // un-pad: gradient of the cropped region only
   float* g = p.gb;
@@ -1542,7 +1548,7 @@ extern "C" int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, 
                           sgq.Tout, st));
     std::swap(g, other);                       // g = d (transposed conv output), length Tout
     float* dw = grads + q->slot_of(pu + "0.weight");
-    DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)C * C * 2 * sizeof(float), st));
+    DMEL_TRY(zero_unless_cleared(dw, (size_t)C * C * 2 * sizeof(float), st));
     for (int k = 0; k < 2; ++k)                // d W[ci, co, k] = sum x[ci, q] d y[co, 2q + k]
       DMEL_TRY(launch_conv_wgrad_strided(sgq.in, g, dw, C, C, 2, k, sgq.Tin, sgq.Tout, 2, k, N, st));
     DMEL_TRY(launch_conv_bgrad(g, grads + q->slot_of(pu + "0.bias"), C, N, sgq.Tout, st));
@@ -1567,7 +1573,7 @@ extern "C" int dmel_quantizer_backward(const dmel_quantizer* q, const float* z, 
     std::swap(g, other);                       // g = d (conv output), length Tout
     const float* xin = i == 0 ? z : sgq.in;
     float* dw = grads + q->slot_of(pd + "0.weight");
-    DMEL_HIP(hipMemsetAsync(dw, 0, (size_t)C * C * 2 * sizeof(float), st));
+    DMEL_TRY(zero_unless_cleared(dw, (size_t)C * C * 2 * sizeof(float), st));
     for (int k = 0; k < 2; ++k)                // d W[co, ci, k] = sum d y[co, q] x[ci, 2q + k]
       DMEL_TRY(launch_conv_wgrad_strided(g, xin, dw, C, C, 2, k, sgq.Tout, sgq.Tin, 2, k, N, st));
     DMEL_TRY(launch_conv_bgrad(g, grads + q->slot_of(pd + "0.bias"), C, N, sgq.Tout, st));
@@ -2001,6 +2007,7 @@ extern "C" int dmel_discriminator_refresh(dmel_discriminator* d, int n, const ch
       DMEL_HIP(hipMemcpyAsync(l.g_dev.p, g, (size_t)l.Cout * sizeof(float), hipMemcpyDeviceToDevice, st));
       DMEL_HIP(hipMemcpyAsync(l.v_dev.p, v, (size_t)l.Cout * inner * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
+    RepackBatch batch(st);      // the 3-9 images of this layer in one launch
     for (int dh = 0; dh < 3; ++dh) {
       {
         RepackSrc src;
@@ -2022,6 +2029,7 @@ extern "C" int dmel_discriminator_refresh(dmel_discriminator* d, int n, const ch
         }
       }
     }
+    DMEL_TRY(batch.flush());
     // the folded weight buffer is reused by the next layer: the launches above are ordered on the same stream
   }
   return DMEL_OK;

@@ -3,6 +3,10 @@
 // What autograd differentiates in the reference: wavenet.py:116-135 (ResidualBlock.forward), :204-225 (WaveNet.forward).
 #include "ops.h"
 
+#include <cstring>
+#include <memory>
+#include <vector>
+
 namespace dmel {
 
 namespace {
@@ -256,67 +260,167 @@ __device__ __forceinline__ int repack_src_row(const RepackArgs& a, int m) {     
   return co >= a.C ? -1 : ph * a.C + co;
 }
 
-__global__ void repack_kernel(RepackArgs a) {
-  const int64_t total = (int64_t)a.Mpad * a.steps * kCK;
-  for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int k = (int)(e % kCK);
-    const int step = (int)((e / kCK) % a.steps);
-    const int m = (int)(e / ((int64_t)kCK * a.steps));
-    int sg = 0, ls = step;
-    if (a.nseg > 1 && ls >= a.nchunk[0] * a.taps[0]) { ls -= a.nchunk[0] * a.taps[0]; sg = 1; }
-    const int ch = ls / a.taps[sg], tp = ls - ch * a.taps[sg];
-    const int ci = ch * kCK + k;
-    const int sr = repack_src_row(a, m);
-    float v = 0.f;
-    if (sr >= 0 && ci < a.Cin[sg]) {
-      const RepackSeg& s = a.seg[sg];
-      const int t = s.rev ? a.taps[sg] - 1 - tp : tp;
-      const int64_t ro = s.pC > 0 ? (int64_t)(sr % s.pC) * s.rs + (int64_t)(sr / s.pC) * s.ps : (int64_t)sr * s.rs;
-      v = s.w[ro + ci * s.cs + t * s.ts];
-    }
-    const int tile = m >> 5, r = m & 31;
-    {  // fp32 image: [tile][step][half][lane][4], lane = 32*(k&1) + r
-      const int h = k & 1, kk = k >> 1, hf = kk >> 2, j = kk & 3, lane = 32 * h + r;
-      a.w[((((int64_t)tile * a.steps + step) * 2 + hf) * 64 + lane) * 4 + j] = v;
-    }
-    {  // bf16 images: [tile][step][(piece)][lane][8], lane = 32*(k>>3) + r
-      const int h = k >> 3, j = k & 7, lane = 32 * h + r;
-      const uint32_t u = __float_as_uint(v);
-      uint16_t rne;
-      if ((u & 0x7fffffffu) > 0x7f800000u) rne = (uint16_t)((u >> 16) | 0x40);
-      else rne = (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
-      a.w16[(((int64_t)tile * a.steps + step) * 64 + lane) * 8 + j] = rne;
-      const float p1 = __uint_as_float(u & 0xffff0000u), r1 = v - p1;
-      const float p2 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u), r2 = r1 - p2;
-      const int64_t base = ((int64_t)tile * a.steps + step) * 3;
-      a.w48[((base + 0) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(p1) >> 16);
-      a.w48[((base + 1) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(p2) >> 16);
-      a.w48[((base + 2) * 64 + lane) * 8 + j] = (uint16_t)(__float_as_uint(r2) >> 16);
-      // fp16 pieces of 2^6 w (conv.h pack_conv; v_cvt_f16_f32 rounds to nearest even and keeps subnormals, like f32_to_f16_bits)
-      const float vs = v * kF16WScale;
-      const _Float16 hi = (_Float16)vs;
-      const _Float16 lo = (_Float16)((vs - (float)hi) * kF16LoScale);
-      const int64_t bh = ((int64_t)tile * a.steps + step) * 2;
-      a.w32h[((bh + 0) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, hi);
-      a.w32h[((bh + 1) * 64 + lane) * 8 + j] = __builtin_bit_cast(uint16_t, lo);
-    }
-    if (step == 0 && k == 0) {
-      float b = 0.f;
-      if (sr >= 0) {
-        const int bi = a.bias_mod > 0 ? sr % a.bias_mod : sr;
-        if (a.b0) b = a.b0[bi];
-        if (a.b1) b += a.b1[bi];
-      }
-      a.bias[m] = b;
-    }
+// One thread per (packed row m, K step, half h): the eight weights k = 8 h .. 8 h + 7 of that row and step, i.e. one 16-byte unit of each
+// 16-bit image (lane 32 h + r of the A fragment) and two of the fp32 image (lanes r and 32 + r, half-step h).  A wave covers the 64 lanes
+// of one (tile, step): 1 KiB contiguous per image and piece.  (Round 2 had one thread per weight writing 2-byte units: 0.6 TB/s.)
+// Jobs of one refresh are batched into ONE launch: the table lives in device memory, `first` holds the first block of every job.
+struct RepackJob {
+  RepackArgs a;
+  int first_block;      // blocks [first_block, next job's first_block) work on this job, 256 units each
+};
+
+__device__ __forceinline__ void repack_unit(const RepackArgs& a, int64_t u) {
+  const int r = (int)(u & 31), h = (int)((u >> 5) & 1);
+  const int64_t q = u >> 6;
+  const int step = (int)(q % a.steps), tile = (int)(q / a.steps);
+  const int m = tile * 32 + r;
+  int sg = 0, ls = step;
+  if (a.nseg > 1 && ls >= a.nchunk[0] * a.taps[0]) { ls -= a.nchunk[0] * a.taps[0]; sg = 1; }
+  const int ch = ls / a.taps[sg], tp = ls - ch * a.taps[sg];
+  const int sr = repack_src_row(a, m);
+  float v[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) v[j] = 0.f;
+  if (sr >= 0) {
+    const RepackSeg& s = a.seg[sg];
+    const int t = s.rev ? a.taps[sg] - 1 - tp : tp;
+    const int64_t ro = (s.pC > 0 ? (int64_t)(sr % s.pC) * s.rs + (int64_t)(sr / s.pC) * s.ps : (int64_t)sr * s.rs) + t * s.ts;
+    const int ci0 = ch * kCK + 8 * h;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (ci0 + j < a.Cin[sg]) v[j] = s.w[ro + (int64_t)(ci0 + j) * s.cs];
   }
+  const int64_t ts = (int64_t)tile * a.steps + step;
+  {  // fp32 image: [tile][step][half][lane][4]; weight k sits in lane 32 (k & 1) + r, half (k >> 3), word (k >> 1) & 3
+    float4* w4 = reinterpret_cast<float4*>(a.w) + (ts * 2 + h) * 64;
+    w4[r] = make_float4(v[0], v[2], v[4], v[6]);
+    w4[32 + r] = make_float4(v[1], v[3], v[5], v[7]);
+  }
+  // 16-bit images: [tile][step][(piece)][lane][8], lane = 32 h + r
+  const int lane = 32 * h + r;
+  uint16_t b16[8], p1[8], p2[8], p3[8], hi[8], lo[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t u32 = __float_as_uint(v[j]);
+    if ((u32 & 0x7fffffffu) > 0x7f800000u) b16[j] = (uint16_t)((u32 >> 16) | 0x40);
+    else b16[j] = (uint16_t)((u32 + 0x7fffu + ((u32 >> 16) & 1u)) >> 16);
+    const float f1 = __uint_as_float(u32 & 0xffff0000u), r1 = v[j] - f1;
+    const float f2 = __uint_as_float(__float_as_uint(r1) & 0xffff0000u), r2 = r1 - f2;
+    p1[j] = (uint16_t)(__float_as_uint(f1) >> 16);
+    p2[j] = (uint16_t)(__float_as_uint(f2) >> 16);
+    p3[j] = (uint16_t)(__float_as_uint(r2) >> 16);
+    // fp16 pieces of 2^6 w (conv.h pack_conv; v_cvt_f16_f32 rounds to nearest even and keeps subnormals, like f32_to_f16_bits)
+    const float vs = v[j] * kF16WScale;
+    const _Float16 fh = (_Float16)vs;
+    const _Float16 fl = (_Float16)((vs - (float)fh) * kF16LoScale);
+    hi[j] = __builtin_bit_cast(uint16_t, fh);
+    lo[j] = __builtin_bit_cast(uint16_t, fl);
+  }
+  auto pack8 = [](const uint16_t (&x)[8]) {
+    return make_uint4((uint32_t)x[0] | ((uint32_t)x[1] << 16), (uint32_t)x[2] | ((uint32_t)x[3] << 16), (uint32_t)x[4] | ((uint32_t)x[5] << 16),
+                      (uint32_t)x[6] | ((uint32_t)x[7] << 16));
+  };
+  reinterpret_cast<uint4*>(a.w16)[ts * 64 + lane] = pack8(b16);
+  uint4* w48 = reinterpret_cast<uint4*>(a.w48) + ts * 3 * 64;
+  w48[lane] = pack8(p1);
+  w48[64 + lane] = pack8(p2);
+  w48[128 + lane] = pack8(p3);
+  uint4* w32h = reinterpret_cast<uint4*>(a.w32h) + ts * 2 * 64;
+  w32h[lane] = pack8(hi);
+  w32h[64 + lane] = pack8(lo);
+  if (step == 0 && h == 0) {
+    float b = 0.f;
+    if (sr >= 0) {
+      const int bi = a.bias_mod > 0 ? sr % a.bias_mod : sr;
+      if (a.b0) b = a.b0[bi];
+      if (a.b1) b += a.b1[bi];
+    }
+    a.bias[m] = b;
+  }
+}
+
+__global__ __launch_bounds__(256) void repack_kernel(const RepackJob* __restrict__ jobs, int njobs) {
+  // the job of this block: last entry whose first_block <= blockIdx.x (uniform: scalar loads)
+  int lo = 0, hi = njobs - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].first_block <= (int)blockIdx.x) lo = mid;
+    else hi = mid - 1;
+  }
+  const RepackJob& jb = jobs[lo];
+  const int64_t units = (int64_t)jb.a.Mpad * jb.a.steps * 2;
+  const int64_t u = (int64_t)((int)blockIdx.x - jb.first_block) * 256 + threadIdx.x;
+  if (u < units) repack_unit(jb.a, u);
+}
+
+namespace {
+// Jobs collected between RepackBatch::begin and ::flush on this thread (a refresh of one module: 2-120 convolutions) go out as one launch.
+struct RepackBatchState {
+  bool open = false;
+  std::vector<RepackJob> jobs;
+  int blocks = 0;
+  // device copies of the tables this thread has launched, by content: the arguments of a module's refresh are the same every optimiser step
+  // (parameter storages do not move), so the upload -- a pageable-memory copy that would make the host wait for the stream -- happens once
+  struct Cached { std::vector<char> bytes; DevBuf dev; };
+  std::vector<std::unique_ptr<Cached>> cache;
+};
+RepackBatchState& repack_state() {
+  static thread_local RepackBatchState s;
+  return s;
+}
+int repack_launch_jobs(RepackBatchState& st, hipStream_t s) {
+  if (st.jobs.empty()) return DMEL_OK;
+  const size_t nbytes = st.jobs.size() * sizeof(RepackJob);
+  const char* raw = reinterpret_cast<const char*>(st.jobs.data());
+  RepackBatchState::Cached* hit = nullptr;
+  for (auto& c : st.cache)
+    if (c->bytes.size() == nbytes && std::memcmp(c->bytes.data(), raw, nbytes) == 0) { hit = c.get(); break; }
+  if (!hit) {
+    if (st.cache.size() >= 64) {      // parameters were re-allocated again and again: drop the oldest table once the stream is done with it
+      DMEL_HIP(hipStreamSynchronize(s));
+      st.cache.erase(st.cache.begin());
+    }
+    auto c = std::make_unique<RepackBatchState::Cached>();
+    c->bytes.assign(raw, raw + nbytes);
+    DMEL_HIP(hipMalloc(&c->dev.p, nbytes));
+    c->dev.bytes = nbytes;
+    DMEL_HIP(hipMemcpyAsync(c->dev.p, c->bytes.data(), nbytes, hipMemcpyHostToDevice, s));
+    hit = c.get();
+    st.cache.push_back(std::move(c));
+  }
+  hipLaunchKernelGGL(repack_kernel, dim3((unsigned)st.blocks), dim3(256), 0, s, reinterpret_cast<const RepackJob*>(hit->dev.p), (int)st.jobs.size());
+  DMEL_HIP(hipGetLastError());
+  return DMEL_OK;
+}
+}  // namespace
+
+RepackBatch::RepackBatch(hipStream_t s) : stream(s) {
+  RepackBatchState& st = repack_state();
+  owner = !st.open;
+  if (owner) { st.open = true; st.jobs.clear(); st.blocks = 0; }
+}
+int RepackBatch::flush() {
+  RepackBatchState& st = repack_state();
+  if (!owner || !st.open) return DMEL_OK;
+  const int rc = repack_launch_jobs(st, stream);
+  st.jobs.clear();
+  st.blocks = 0;
+  return rc;
+}
+RepackBatch::~RepackBatch() {
+  if (!owner) return;
+  RepackBatchState& st = repack_state();
+  st.open = false;      // an error path left jobs behind: they are dropped with the error the caller already reports
+  st.jobs.clear();
+  st.blocks = 0;
 }
 
 int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t s) {
   const PackDesc& d = pc.d;
   DMEL_CHECK_ARG(pc.w.p && pc.w16.p && pc.w48.p && pc.w32h.p && pc.bias.p, "repack: the convolution was never packed");
   DMEL_CHECK_ARG(d.nseg >= 1 && d.nseg <= 2 && src.seg[0].w && (d.nseg == 1 || src.seg[1].w), "repack: missing source tensor");
-  RepackArgs a{};
+  RepackJob jb{};
+  RepackArgs& a = jb.a;
   a.seg[0] = src.seg[0]; a.seg[1] = src.seg[1];
   a.b0 = src.b0; a.b1 = src.b1; a.bias_mod = src.bias_mod;
   a.w = pc.w.as<float>(); a.w16 = pc.w16.as<uint16_t>(); a.w48 = pc.w48.as<uint16_t>(); a.w32h = pc.w32h.as<uint16_t>(); a.bias = pc.bias.as<float>();
@@ -325,10 +429,20 @@ int launch_repack(PackedConv& pc, const RepackSrc& src, hipStream_t s) {
     a.Cin[i] = d.seg[i].Cin; a.taps[i] = d.seg[i].taps; a.nchunk[i] = (d.seg[i].Cin + kCK - 1) / kCK;
   }
   if (d.nseg == 1) { a.Cin[1] = 0; a.taps[1] = 1; a.nchunk[1] = 0; }
-  const int64_t total = (int64_t)pc.Mpad * pc.steps * kCK;
-  hipLaunchKernelGGL(repack_kernel, dim3(blocks_for(total)), dim3(256), 0, s, a);
-  DMEL_HIP(hipGetLastError());
-  return DMEL_OK;
+  const int64_t units = (int64_t)pc.Mpad * pc.steps * 2;
+  const int64_t nb = (units + 255) / 256;
+  RepackBatchState& st = repack_state();
+  DMEL_CHECK_ARG(nb > 0 && (int64_t)st.blocks + nb < ((int64_t)1 << 30), "repack: image too large");
+  const bool batched = st.open;
+  if (!batched) { st.jobs.clear(); st.blocks = 0; }
+  jb.first_block = st.blocks;
+  st.jobs.push_back(jb);
+  st.blocks += (int)nb;
+  if (batched) return DMEL_OK;      // RepackBatch::flush launches
+  const int rc = repack_launch_jobs(st, s);
+  st.jobs.clear();
+  st.blocks = 0;
+  return rc;
 }
 
 #define DMEL_EW_LAUNCH(kernel, total, bytes_per_elem, ...)                                  \
@@ -379,8 +493,8 @@ int launch_ln_bwd(const float* dh1, const float* h0, const float* ln_w, float* d
   DMEL_CHECK_ARG(N > 0 && N <= 65535 && C > 0 && T > 0, "ln_bwd: bad shape");
   const size_t lds = ((size_t)2 * C * (kLnTile + 1) + 4 * kLnTile) * sizeof(float);
   DMEL_CHECK_ARG(lds <= 64 * 1024, "ln_bwd: %d channels exceed the LDS tile", C);
-  DMEL_HIP(hipMemsetAsync(dln_w, 0, (size_t)C * sizeof(float), s));
-  DMEL_HIP(hipMemsetAsync(dln_b, 0, (size_t)C * sizeof(float), s));
+  DMEL_TRY(zero_unless_cleared(dln_w, (size_t)C * sizeof(float), s));
+  DMEL_TRY(zero_unless_cleared(dln_b, (size_t)C * sizeof(float), s));
   dim3 grid((unsigned)((T + kLnTile - 1) / kLnTile), (unsigned)N);
   hipLaunchKernelGGL(ln_bwd_kernel, grid, dim3(256), lds, s, dh1, h0, ln_w, dh0, dln_w, dln_b, C, T, 1e-6f);
   DMEL_HIP(hipGetLastError());
