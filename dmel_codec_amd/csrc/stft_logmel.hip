@@ -19,8 +19,22 @@
 
 namespace dmel {
 
-constexpr int kFramesPerWG = 32;
-constexpr int kWaves = 4;
+// A/B switches (tools/build_variant.sh): waves per workgroup, and up to which P the window / pass-1 twiddles stay in registers
+#ifndef DMEL_STFT_WAVES
+#define DMEL_STFT_WAVES 4
+#endif
+#ifndef DMEL_STFT_REGTAB_MAXP
+#define DMEL_STFT_REGTAB_MAXP 8
+#endif
+#ifndef DMEL_STFT_WPE
+#define DMEL_STFT_WPE 0
+#endif
+#ifndef DMEL_STFT_FRAMES
+#define DMEL_STFT_FRAMES 32
+#endif
+constexpr int kFramesPerWG = DMEL_STFT_FRAMES;
+constexpr int kWaves = DMEL_STFT_WAVES;
+constexpr int kThreads = 64 * kWaves;
 constexpr int kFramesPerWave = kFramesPerWG / kWaves;
 constexpr int kMaxMels = 128;
 
@@ -124,7 +138,10 @@ constexpr int kMaxMelW = 2304;   // non-zero mel weights (each FFT bin feeds at 
 // 8 x 8 with two LDS transposes (passes 2 and 3: P*8 independent 8-point DFTs each, i.e. P/8 per lane; for P = 4 half
 // the lanes idle in those passes).  Output index k = k1 + P (j1 + 8 j2).
 template <int P>
-__global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const float* __restrict__ audio,
+#if DMEL_STFT_WPE
+__attribute__((amdgpu_waves_per_eu(DMEL_STFT_WPE, DMEL_STFT_WPE)))
+#endif
+__global__ __launch_bounds__(kThreads) void stft_logmel_kernel(StftTables tb, const float* __restrict__ audio,
                                                           int64_t row_stride, const int64_t* __restrict__ lengths,
                                                           float* __restrict__ out, float* __restrict__ linear, int64_t L, int64_t T,
                                                           int hop, int pad, int n_mels, int mel_passes) {
@@ -134,7 +151,7 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
   float* mag_all = smem_stft + 2 * kWaves * EX;                   // [kWaves][H+8]
   float* chw = mag_all + kWaves * (H + 8);                        // [mel_passes * 64][kMelChunk] chunk weights (LDS sized per plan)
   int* chk0 = reinterpret_cast<int*>(chw + mel_passes * 64 * kMelChunk);   // [mel_passes * 64] first bin of every chunk
-  float (*tile)[kFramesPerWG + 1] = reinterpret_cast<float (*)[kFramesPerWG + 1]>(chk0 + mel_passes * 64);   // [kMaxMels][33]
+  float (*tile)[kFramesPerWG + 1] = reinterpret_cast<float (*)[kFramesPerWG + 1]>(chk0 + mel_passes * 64);   // [n_mels][33]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -143,12 +160,12 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
   const int64_t t0 = (int64_t)blockIdx.x * kFramesPerWG;
   const float* x = audio + (int64_t)b * row_stride;
 
-  for (int i = tid; i < mel_passes * 64 * kMelChunk; i += 256) chw[i] = tb.ch_w[i];
-  for (int i = tid; i < mel_passes * 64; i += 256) chk0[i] = tb.ch_k0[i];
+  for (int i = tid; i < mel_passes * 64 * kMelChunk; i += kThreads) chw[i] = tb.ch_w[i];
+  for (int i = tid; i < mel_passes * 64; i += kThreads) chk0[i] = tb.ch_k0[i];
   if (tid < kWaves * 7) mag_all[(tid / 7) * (H + 8) + H + 1 + tid % 7] = 0.f;   // pad bins: read (times a zero weight) by the last chunks
 
   // per-lane constants kept in registers across the wave's frames (window and pass-1 twiddles only while they fit)
-  constexpr bool kRegTables = P <= 8;
+  constexpr bool kRegTables = P <= DMEL_STFT_REGTAB_MAXP;
   cf wz[kRegTables ? P : 1], w1[kRegTables ? P : 1], w2[8], wr[NR];
   if constexpr (kRegTables) {
 #pragma unroll
@@ -296,15 +313,16 @@ __global__ __launch_bounds__(256) void stft_logmel_kernel(StftTables tb, const f
   if (!out) return;
   const int64_t n_valid = lengths ? lengths[b] / hop : T;
   float* o = out + (int64_t)b * n_mels * T;
-  for (int idx = tid; idx < n_mels * kFramesPerWG; idx += 256) {
+  for (int idx = tid; idx < n_mels * kFramesPerWG; idx += kThreads) {
     const int m = idx / kFramesPerWG, f = idx % kFramesPerWG;
     const int64_t t = t0 + f;
     if (t < T) o[(int64_t)m * T + t] = (t < n_valid) ? tile[m][f] : 0.f;
   }
 }
 
-template <int P> static size_t stft_lds_bytes(int mel_passes = kMaxMelPasses) {
-  return (size_t)(2 * kWaves * P * 72 + kWaves * (64 * P + 8) + mel_passes * 64 * (kMelChunk + 1) + kMaxMels * (kFramesPerWG + 1)) *
+// the output tile is sized by the plan's band count (80 bands at n_fft = 1024: 48.6 KB, three workgroups per CU instead of two)
+template <int P> static size_t stft_lds_bytes(int mel_passes = kMaxMelPasses, int n_mels = kMaxMels) {
+  return (size_t)(2 * kWaves * P * 72 + kWaves * (64 * P + 8) + mel_passes * 64 * (kMelChunk + 1) + n_mels * (kFramesPerWG + 1)) *
          sizeof(float);
 }
 
@@ -515,15 +533,15 @@ extern "C" int dmel_stft_f32(const dmel_stft_plan* p, const float* audio, int64_
     ProfScope ps("stft_logmel", s, 0.0, (double)B * (4.0 * (double)L + 4.0 * p->n_mels * (double)T));
     switch (p->n_fft) {
       case 512:
-        hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(256), stft_lds_bytes<4>(p->mel_passes), s, tb, audio, row_stride, lengths, out,
+        hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(kThreads), stft_lds_bytes<4>(p->mel_passes, p->n_mels), s, tb, audio, row_stride, lengths, out,
                            linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
         break;
       case 1024:
-        hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(256), stft_lds_bytes<8>(p->mel_passes), s, tb, audio, row_stride, lengths, out,
+        hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(kThreads), stft_lds_bytes<8>(p->mel_passes, p->n_mels), s, tb, audio, row_stride, lengths, out,
                            linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
         break;
       default:
-        hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(256), stft_lds_bytes<16>(p->mel_passes), s, tb, audio, row_stride, lengths,
+        hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(kThreads), stft_lds_bytes<16>(p->mel_passes, p->n_mels), s, tb, audio, row_stride, lengths,
                            out, linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
     }
   }

@@ -39,6 +39,22 @@ class NativeModule(nn.Module):
         self._grads_delivered = False  # while armed: parameter gradients were pointed at the flat buffer ...
         self._grads_submitted = False  # ... and the buffer went to the reducer (GradReducer.finish checks the pair)
 
+    # -- copies --------------------------------------------------------------------------------
+    def __getstate__(self):
+        """copy.deepcopy / pickle: a copy builds its OWN native handle and workspace on first use (the handle is an address inside the
+        library: copied by value, the copy would free the original's, or run in its scratch)."""
+        st = self.__dict__.copy()
+        st["_handle"], st["_handle_versions"] = None, None
+        st["_ws"] = _lib.Workspace()
+        st.pop("_train_calls", None)          # a WeakSet does not pickle; __setstate__ makes a new one
+        st["_grad_sink"], st["_backward_ctx"] = None, None
+        st["_grads_delivered"], st["_grads_submitted"] = False, False
+        return st
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._train_calls = weakref.WeakSet()
+
     # -- handle life cycle ---------------------------------------------------------------------
     def _native_state(self) -> dict:
         return self.state_dict()

@@ -46,6 +46,11 @@ class LinearSpectrogram(nn.Module):
         _lib.check(_lib.lib().dmel_stft_plan_mel_basis(self._get_plan(), out.data_ptr()), "stft_plan_mel_basis")
         return out
 
+    def __getstate__(self):      # copies / pickles create their own plan
+        st = self.__dict__.copy()
+        st["_plan"] = None
+        return st
+
     def __del__(self):
         if getattr(self, "_plan", None) is not None and _lib._lib is not None:
             _lib._lib.dmel_stft_plan_destroy(self._plan)

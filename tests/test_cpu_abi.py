@@ -254,3 +254,30 @@ def test_handle_cache_is_tied_to_the_tensor_not_to_its_address():
     assert cache.get(ts[0], 0) == "t0"                                  # touch 0: 1 is now the oldest
     cache.put(ts[3], 0, "t3")
     assert destroyed[-1] == "t1" and cache.get(ts[0], 0) == "t0" and cache.get(ts[2], 0) == "t2" and cache.get(ts[3], 0) == "t3"
+
+
+def test_copies_of_a_mirror_never_share_its_native_handle():
+    """copy.deepcopy (what dmel_codec_amd.pipeline.CodecLanes makes its lanes with) and pickling of a mirror module: the copy carries no
+    handle, no plan and no workspace of the original -- a handle is an address inside the library; copied by value, the copy's first
+    native() would free the original's."""
+    import copy
+    import pickle
+    from dmel_codec_amd.models.modules.wavenet import WaveNet
+    from dmel_codec_amd.utils.spectrogram import LogMelSpectrogram
+    m = WaveNet(input_channels=10, output_channels=10, residual_channels=16, residual_layers=2, dilation_cycle=2)
+    m._handle, m._handle_versions = 0xDEAD0000, ("stale",)      # pretend a handle exists (never dereferenced: reset below)
+    m._ws.buf = torch.zeros(4)
+    try:
+        for c in (copy.deepcopy(m), pickle.loads(pickle.dumps(m))):
+            assert c._handle is None and c._handle_versions is None and c._ws is not m._ws and c._ws.buf is None
+            assert len(c._train_calls) == 0 and c._grad_sink is None
+            assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), c.state_dict().values()))
+        assert m._handle == 0xDEAD0000
+    finally:
+        m._handle = None      # or __del__ would hand the fake address to the library
+    s = LogMelSpectrogram(sample_rate=24000, n_fft=1024, win_length=1024, hop_length=256, n_mels=80)
+    s.spectrogram._plan = 0xBEEF0000
+    try:
+        assert copy.deepcopy(s).spectrogram._plan is None
+    finally:
+        s.spectrogram._plan = None

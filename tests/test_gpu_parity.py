@@ -698,6 +698,40 @@ def test_incremental_decode_with_state_carry(dev, pattern):
     assert torch.equal(mel_g, mel)
 
 
+def test_lanes_match_sequential(dev):
+    """dmel_codec_amd.pipeline.CodecLanes: four batches dealt to two lanes (replicas on their own streams, in flight together) give the
+    ids and waveforms of the same four batches through the single codec one after the other, bit for bit -- same kernels, same weights,
+    and the decoder's Gaussian input is drawn in submission order."""
+    from dmel_codec_amd.pipeline import CodecLanes
+    codec = make_codec(720, n_mels=80, dmel_groups=8, encoder_layers=2, decoder_layers=3).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    L = 24000
+    batches = [(0.3 * torch.randn(3, 1, L, generator=gen)).to(dev) for _ in range(4)]
+    lens = [torch.tensor([L, L - 700 * (i + 1), L // 2], device=dev) for i in range(4)]
+    torch.manual_seed(99)
+    ref = []
+    for a, l in zip(batches, lens):
+        ids, il = codec.encode(a, l)
+        wav, _ = codec.decode(ids, il, return_audios=True)
+        ref.append((ids.clone(), wav.clone()))
+    torch.cuda.synchronize()
+    lanes = CodecLanes(codec, 2)
+    assert len(lanes) == 2 and lanes.codecs[1] is not codec and lanes.codecs[1].encoder._handle is None      # a copy builds its own handle
+    torch.manual_seed(99)
+    results = [lanes.roundtrip(a, l) for a, l in zip(batches, lens)]
+    assert lanes.codecs[1].encoder._handle is not None and lanes.codecs[1].encoder._handle != codec.encoder._handle
+    for (ids_ref, wav_ref), r in zip(ref, results):
+        ids, il, wav = r.wait()
+        assert torch.equal(ids, ids_ref)
+        assert torch.equal(wav, wav_ref)
+    lanes.synchronize()
+    # weights changed on lane 0 reach the other lanes through refresh()
+    with torch.no_grad():
+        codec.quality_projection.bias.add_(0.25)
+    lanes.refresh()
+    assert torch.equal(lanes.codecs[1].quality_projection.bias, codec.quality_projection.bias)
+
+
 def test_streaming_decode_by_graph_replay_is_bit_identical(dev):
     """VQGAN.decode_stream(use_graph=True): once the stream is in its steady state a push of `chunk_tokens` tokens is one HIP-graph replay
     (quantiser window, every WaveNet block's new columns, vocoder window: ~250 launches -> 1).  The concatenated output must still be
