@@ -5,7 +5,7 @@
 Workload (BASELINE.json configs[1]): full codec inference at 24 kHz, 80 mel bins, 8 FSQ groups, BigVGAN-base
 vocoder, batch 32 of 1 s clips per GPU, fp32.  A "step" is one encode() + decode(return_audios=True) over one
 batch already resident in HBM; weights are seeded random (the reference ships none), audio is synthetic.
-Steps are independent batches: `--lanes` (default 2) of them are in flight per GPU at a time (dmel_codec_amd/pipeline.py); the
+Steps are independent batches: `--lanes` (default 3) of them are in flight per GPU at a time (dmel_codec_amd/pipeline.py); the
 line also carries the one-batch-at-a-time figure (`one_batch_at_a_time`) timed in the same run.
 One process per GPU; utterances shard across ranks with no data-path collective (weak scaling).  Rank 0 prints
 ONE JSON line with the whole-job rate, the roofline of the dominant kernel family (the implicit-GEMM convolutions:
@@ -261,9 +261,10 @@ def main() -> None:
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work for the baseline (0 = skip)")
     ap.add_argument("--median-steps", type=int, default=100,
                     help="extra steps timed one by one with events for the median / p10 / p90 of the step time (0 = skip)")
-    ap.add_argument("--streams", type=int, default=3, choices=(1, 3),
-                    help="streams BigVGAN's AMP blocks overlap on in the timed region (1 = serialised, for rocprofv3 runs)")
-    ap.add_argument("--lanes", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=1, choices=(1, 3),
+                    help="streams the three AMP blocks of a BigVGAN stage run on WITHIN one batch (3 = overlapped: the round-1/2 default; with "
+                         "several batches in flight the lanes already fill the chip and 1 measures faster: profiles/r03_lanes_sweep.txt)")
+    ap.add_argument("--lanes", type=int, default=3,
                     help="batches in flight per GPU in the timed region (dmel_codec_amd.pipeline.CodecLanes: replicas of the codec on their "
                          "own streams, batches dealt round-robin; 1 = one batch at a time, the round-1/2 form, also timed and reported)")
     ap.add_argument("--decode-precision", default="fp32", choices=("fp32", "fp32_bf16x3", "bf16"),
