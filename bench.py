@@ -285,7 +285,7 @@ def main() -> None:
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DMEL_BENCH_FORCE_DIST") == "1":      # the second: tests drive the RCCL control path with one rank
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist_mod.init_process_group("nccl", device_id=dev)    # RCCL
@@ -421,6 +421,7 @@ def main() -> None:
             "ms_per_step_events": ({"what": "latency of one batch alone (no other batch in flight)", "n": len(per_step_ms), "median": round(per_step_ms[len(per_step_ms) // 2], 3),
                                     "p10": round(per_step_ms[len(per_step_ms) // 10], 3),
                                     "p90": round(per_step_ms[(9 * len(per_step_ms)) // 10], 3)} if per_step_ms else None),
+            "process_group": (dist.get_backend() if dist is not None else None),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 operands, f32 accumulate in the decode convolutions (opt-in mode); f32 elsewhere" if bf16 else "f32",
             "data": "synthetic",

@@ -345,6 +345,41 @@ def test_two_data_parallel_ranks_of_the_real_training_step(dev):
     assert '"ranks_identical": true' in r.stdout
 
 
+def test_training_step_over_rccl_single_rank(dev):
+    """The same rehearsal over the transport the multi-GPU run uses: backend "nccl" (= RCCL), one rank (RCCL wants one device per rank and
+    the box has one).  No peer, but everything the 8-GPU job executes on this side of the wire does run: communicator creation with
+    device_id, ReduceOp.AVG (gloo has none: the branch never ran before), asynchronous all-reduces issued from inside the native backward
+    on RCCL's own stream, Work.wait before the clip, barrier, all_gather_object.  Parameters must equal the single-process reference."""
+    import subprocess, sys
+    from conftest import ROOT
+    torch.cuda.synchronize()
+    env = dict(os.environ, DMEL_REHEARSAL_WORLD="1", DMEL_REHEARSAL_BACKEND="nccl", DMEL_REHEARSAL_TIMEOUT="240", NCCL_SOCKET_IFNAME="lo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_rehearsal.py")], capture_output=True, text=True, timeout=600, env=env)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
+    assert r.returncode == 0 and "PASS" in r.stdout, tail
+    assert '"backend": "nccl"' in r.stdout and '"ranks_identical": true' in r.stdout, tail
+    from conftest import report
+    report("[rccl] " + [l for l in r.stdout.splitlines() if l.startswith("{")][0])
+
+
+def test_bench_control_path_over_rccl_single_rank(dev):
+    """bench.py's multi-GPU control path -- init_process_group("nccl", device_id=...), the barrier on both sides of the timed region,
+    the MAX / all-gather of the per-rank times -- under the driver's launcher with one rank (DMEL_BENCH_FORCE_DIST=1 creates the process
+    group although WORLD_SIZE is 1): the first run of those lines on RCCL."""
+    import json, subprocess, sys
+    from conftest import ROOT
+    torch.cuda.synchronize()
+    env = dict(os.environ, DMEL_BENCH_FORCE_DIST="1", NCCL_SOCKET_IFNAME="lo")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29500 + os.getpid() % 500), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2",
+                        "--warmup", "1", "--cpu-budget", "0", "--median-steps", "0"], capture_output=True, text=True, timeout=600, env=env,
+                       cwd=ROOT)
+    tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
+    assert r.returncode == 0, tail
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and len(line["ms_per_step_by_rank"]) == 1 and line.get("process_group") == "nccl", tail
+
+
 def test_train_codec_under_torch_distributed_run_two_ranks(dev, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 train_codec.py ...` -- the launch line of INTEGRATION.md -- on this one GPU
     (DMEL_TRAIN_SHARE_DEVICE=1 points both ranks at device 0, DMEL_DIST_BACKEND=gloo because RCCL wants one GPU per rank): trainer

@@ -13,6 +13,9 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 WORLD = int(os.environ.get("DMEL_REHEARSAL_WORLD", "2"))
+# gloo (default: several ranks on one device) or nccl = RCCL (one rank per device: on a one-GPU box that is WORLD = 1 -- the transport the
+# 8-GPU run uses, with its AVG reduction, communicator stream and Work handles, just without a peer)
+BACKEND = os.environ.get("DMEL_REHEARSAL_BACKEND", "gloo")
 
 
 def build():
@@ -44,7 +47,10 @@ def worker():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo")
+    if BACKEND == "nccl":
+        dist.init_process_group("nccl", device_id=dev)
+    else:
+        dist.init_process_group("gloo")
     codec = build().to(dev)
     codec.grad_reducer.record_events = True
     logs = []
@@ -61,7 +67,7 @@ def worker():
     same = all(g == gathered[0] for g in gathered)
     if rank == 0:
         torch.save({k: v.detach().cpu() for k, v in codec.state_dict().items()}, os.environ["DMEL_REHEARSAL_OUT"])
-        print(json.dumps({"ranks_identical": same, "n_collectives": len(issues), "arms": sum(1 for e in ev if e[0] == "arm"),
+        print(json.dumps({"backend": dist.get_backend(), "world": world, "ranks_identical": same, "n_collectives": len(issues), "arms": sum(1 for e in ev if e[0] == "arm"),
                           "loss_mel_rank0": [l["train/generator/loss_mel"] for l in logs]}), flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -127,7 +133,13 @@ def main():
         env = dict(os.environ, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(WORLD), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    DMEL_REHEARSAL_OUT=out)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)], env=env))
-    rcs = [p.wait(timeout=600) for p in procs]
+    try:
+        rcs = [p.wait(timeout=int(os.environ.get("DMEL_REHEARSAL_TIMEOUT", "600"))) for p in procs]
+    except subprocess.TimeoutExpired:
+        for p in procs:      # exactly the processes started above
+            p.kill()
+        print("FAIL: a rank did not finish in time")
+        sys.exit(1)
     if any(rcs):
         print(f"FAIL: rank exit codes {rcs}")
         sys.exit(1)
