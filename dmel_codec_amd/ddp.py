@@ -11,8 +11,9 @@ flatten / copy-back passes.  The decoder WaveNet hands its buffer over block by 
 Robustness: outstanding training forwards are tracked by weak references to their autograd contexts, so a graph dropped
 without backward cannot block later exchanges; `finish()` raises if a module produced gradients that never left; `exchange()` is the
 try/finally form of arm / backward / finish; `broadcast_parameters()` makes rank 0's weights everyone's before the first step and
-`check_parameters_in_sync()` compares a checksum across ranks.  The RCCL transport (backend "nccl", ReduceOp.AVG) has NOT run on hardware
-yet: every multi-rank test uses gloo.
+`check_parameters_in_sync()` compares a checksum across ranks.  The RCCL transport (backend "nccl", ReduceOp.AVG) has run with ONE rank only
+(tests/test_gpu_train.py::test_training_step_over_rccl_single_rank: all code on this side of the wire, no peer); every multi-rank test
+uses gloo.
 
 Every rank issues the same collectives in the same order by construction: the order is the order in which the (static) module graph is
 walked backwards, never which `.grad` happens to be None on a rank.  torch.distributed's NCCL (= RCCL) process group runs a collective
@@ -21,10 +22,20 @@ is the side stream + event pair of the design, provided by the backend.  Under g
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
+
+
+def _exchanging(group=None) -> bool:
+    """Is there anybody to exchange with?  A one-rank group normally skips every collective; DMEL_DDP_EXERCISE_SINGLE_RANK=1 runs them
+    anyway (tools/ddp_rehearsal.py on a one-GPU box: RCCL wants one device per rank, so the only way to put the RCCL code path -- AVG,
+    communicator stream, Work handles -- under test there is a group of one)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size(group) > 1 or os.environ.get("DMEL_DDP_EXERCISE_SINGLE_RANK") == "1"
 
 
 class GradReducer:
@@ -39,7 +50,7 @@ class GradReducer:
     # ---------------------------------------------------------------------------------------------------------
     @property
     def active(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return _exchanging(self.group)
 
     def _avg_op(self):
         # RCCL averages inside the collective; gloo has no AVG: sum, then one scale pass after the wait
@@ -175,7 +186,7 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> i
     """Rank `src`'s parameters and buffers become every rank's (what Lightning's DDP wrapper does when it is constructed;
     train_codec.py:49-55 relies on it): identical seeds are then a convenience, not the thing consistency rests on.  Floating tensors
     travel in chunks of one flat message per dtype; returns the number of tensors sent."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchanging(group):
         return 0
     tensors = _flat_state(module)
     by_kind: dict = {}
@@ -196,7 +207,7 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, group=None) -> i
 def check_parameters_in_sync(module: torch.nn.Module, group=None, what: str = "parameters") -> None:
     """Raise if the ranks hold different parameters: every rank contributes (sum, sum of squares, count) of its floating tensors in
     float64 and the MIN and MAX over ranks must agree exactly (bit-identical weights give bit-identical sums)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _exchanging(group):
         return
     tensors = [t for t in _flat_state(module) if t.is_floating_point()]
     dev = tensors[0].device if tensors else torch.device("cpu")

@@ -353,13 +353,18 @@ def test_training_step_over_rccl_single_rank(dev):
     import subprocess, sys
     from conftest import ROOT
     torch.cuda.synchronize()
-    env = dict(os.environ, DMEL_REHEARSAL_WORLD="1", DMEL_REHEARSAL_BACKEND="nccl", DMEL_REHEARSAL_TIMEOUT="240", NCCL_SOCKET_IFNAME="lo")
+    env = dict(os.environ, DMEL_REHEARSAL_WORLD="1", DMEL_REHEARSAL_BACKEND="nccl", DMEL_REHEARSAL_TIMEOUT="240", NCCL_SOCKET_IFNAME="lo",
+               DMEL_DDP_EXERCISE_SINGLE_RANK="1")      # a group of one normally skips every collective
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ddp_rehearsal.py")], capture_output=True, text=True, timeout=600, env=env)
     tail = "\n".join((r.stdout + r.stderr).splitlines()[-12:])
     assert r.returncode == 0 and "PASS" in r.stdout, tail
     assert '"backend": "nccl"' in r.stdout and '"ranks_identical": true' in r.stdout, tail
+    import json
     from conftest import report
-    report("[rccl] " + [l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][0]
+    report("[rccl] " + line)
+    rec = json.loads(line)
+    assert rec["n_collectives"] >= 8 and rec["arms"] == 4, line      # two steps x (discriminator pass + generator pass), block-wise messages
 
 
 def test_bench_control_path_over_rccl_single_rank(dev):
