@@ -2,6 +2,7 @@
 #include "common.h"
 
 #include <map>
+#include <tuple>
 #include <atomic>
 #include <mutex>
 
@@ -70,11 +71,12 @@ using namespace dmel;
 
 extern "C" const char* dmel_last_error(void) { return g_err.c_str(); }
 namespace dmel {
-DevBuf* thread_scratch(int which) {
-  static thread_local std::map<std::pair<int, int>, DevBuf> bufs;
+DevBuf* thread_scratch(int which, hipStream_t stream) {
+  // deliberately leaked (common.h): no hipFree from a thread_local destructor after the runtime is gone
+  static thread_local auto* bufs = new std::map<std::tuple<int, int, hipStream_t>, DevBuf>();
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
-  return &bufs[{dev, which}];
+  return &(*bufs)[std::make_tuple(dev, which, stream)];
 }
 namespace {
 struct ClearedState { const char* lo = nullptr; const char* hi = nullptr; };

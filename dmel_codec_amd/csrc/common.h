@@ -113,9 +113,11 @@ struct DevBuf {
   template <class T> T* as() const { return reinterpret_cast<T*>(p); }
 };
 
-// Library-owned scratch of the calling thread on the CURRENT device (a process normally drives one GPU; a thread that moves between devices
-// gets one buffer per device instead of a pointer into another GPU's memory).
-DevBuf* thread_scratch(int which);      // which: 0 absmax ring, 1 weight-gradient partial tiles, 2 folded discriminator weights
+// Library-owned scratch of the calling thread, per (current device, stream, purpose): two streams driven by one thread -- two models, a
+// side-stream backward, the lanes of dmel_codec_amd/pipeline.py -- must not share partial tiles or folded weights (launches are ordered
+// within a stream only).  Never freed: thread_local destructors would call hipFree at thread / process exit, possibly after the HIP
+// runtime has shut down; the buffers (a few MB per stream that ever trained) go with the process.
+DevBuf* thread_scratch(int which, hipStream_t stream);      // which: 0 absmax ring, 1 weight-gradient partial tiles, 2 folded discriminator weights
 
 // A backward pass clears its whole flat gradient buffer with ONE memset and declares the range here; launches inside it that would clear
 // their own slot first (weight / bias gradients that accumulate with atomics) ask zero_unless_cleared and skip theirs -- round 2 issued

@@ -595,8 +595,8 @@ static bool wgrad_big_tile() {
 int launch_absmax(const float* v, int64_t n, hipStream_t st, const uint32_t** out) {
   // a ring of device words: launches of one thread are ordered on their stream; the ring keeps earlier launches' words alive while later
   // ones are queued
-  DevBuf& ring = *thread_scratch(0);
-  static thread_local unsigned next = 0;
+  DevBuf& ring = *thread_scratch(0, st);
+  static thread_local unsigned next = 0;      // one counter for all rings of the thread: a ring is only ever entered at its own slots
   constexpr unsigned kSlots = 1024;
   if (!ring.p) {
     DMEL_HIP(hipMalloc(&ring.p, kSlots * sizeof(uint32_t)));
@@ -649,9 +649,9 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
              hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_wgrad_f16g_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kWgF16gLds) == hipSuccess;
     }();
     if (!attr_ok) { set_error("conv_wgrad: could not raise the dynamic LDS limit to %zu bytes", kWgF16gLds); return DMEL_EUNSUPPORTED; }
-    // partial tiles of all workgroups: library-owned scratch, reused by every launch of this thread (launches and their reductions are
-    // ordered on the stream; a second stream driven by the same thread would need its own buffer)
-    DevBuf& scratch = *thread_scratch(1);
+    // partial tiles of all workgroups: library-owned scratch of this (thread, stream), reused by every launch on it (launches and their
+    // reductions are ordered on the stream)
+    DevBuf& scratch = *thread_scratch(1, st);
     const size_t need = (size_t)tn * tm * groups * slices * 3 * 4096 * sizeof(float);
     if (scratch.bytes < need) {
       DMEL_HIP(hipStreamSynchronize(st));

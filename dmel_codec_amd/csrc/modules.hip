@@ -1983,7 +1983,7 @@ extern "C" int dmel_discriminator_refresh(dmel_discriminator* d, int n, const ch
     dev[keys[i]] = device_tensors[i];
   }
   hipStream_t st = (hipStream_t)stream;
-  DevBuf& fold = *thread_scratch(2);
+  DevBuf& fold = *thread_scratch(2, st);
   const size_t need = (size_t)1024 * 512 * 9 * sizeof(float);
   if (fold.bytes < need) {
     fold.release();

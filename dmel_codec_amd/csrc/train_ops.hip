@@ -361,12 +361,12 @@ struct RepackBatchState {
   int blocks = 0;
   // device copies of the tables this thread has launched, by content: the arguments of a module's refresh are the same every optimiser step
   // (parameter storages do not move), so the upload -- a pageable-memory copy that would make the host wait for the stream -- happens once
-  struct Cached { std::vector<char> bytes; DevBuf dev; };
+  struct Cached { std::vector<char> bytes; DevBuf dev; hipStream_t stream; };      // uploaded ON that stream: another stream uploads its own
   std::vector<std::unique_ptr<Cached>> cache;
 };
 RepackBatchState& repack_state() {
-  static thread_local RepackBatchState s;
-  return s;
+  static thread_local RepackBatchState* s = new RepackBatchState();      // leaked on purpose: see thread_scratch (common.h)
+  return *s;
 }
 int repack_launch_jobs(RepackBatchState& st, hipStream_t s) {
   if (st.jobs.empty()) return DMEL_OK;
@@ -374,7 +374,7 @@ int repack_launch_jobs(RepackBatchState& st, hipStream_t s) {
   const char* raw = reinterpret_cast<const char*>(st.jobs.data());
   RepackBatchState::Cached* hit = nullptr;
   for (auto& c : st.cache)
-    if (c->bytes.size() == nbytes && std::memcmp(c->bytes.data(), raw, nbytes) == 0) { hit = c.get(); break; }
+    if (c->stream == s && c->bytes.size() == nbytes && std::memcmp(c->bytes.data(), raw, nbytes) == 0) { hit = c.get(); break; }
   if (!hit) {
     if (st.cache.size() >= 64) {      // parameters were re-allocated again and again: drop the oldest table once the stream is done with it
       DMEL_HIP(hipStreamSynchronize(s));
@@ -382,6 +382,7 @@ int repack_launch_jobs(RepackBatchState& st, hipStream_t s) {
     }
     auto c = std::make_unique<RepackBatchState::Cached>();
     c->bytes.assign(raw, raw + nbytes);
+    c->stream = s;
     DMEL_HIP(hipMalloc(&c->dev.p, nbytes));
     c->dev.bytes = nbytes;
     DMEL_HIP(hipMemcpyAsync(c->dev.p, c->bytes.data(), nbytes, hipMemcpyHostToDevice, s));

@@ -45,14 +45,15 @@ class SyntheticDataModule:
                 break
         return collate_clips(clips)
 
-    def _loader(self, n_batches: int, budget: float, salt: int) -> Iterator[dict]:
+    def _loader(self, n_batches: int, budget: float, salt: int, epoch: int) -> Iterator[dict]:
         rank = int(os.environ.get("RANK", "0"))
         for i in range(n_batches):
-            gen = torch.Generator().manual_seed(self.seed + 1000003 * salt + 7919 * self.epoch + 104729 * rank + i)
+            gen = torch.Generator().manual_seed(self.seed + 1000003 * salt + 7919 * epoch + 104729 * rank + i)
             yield self._batch(gen, budget)
 
     def train_dataloader(self):
-        return self._loader(self.train_batches_per_epoch, self.train_max_durations, 1)
+        return self._loader(self.train_batches_per_epoch, self.train_max_durations, 1, self.epoch)
 
     def val_dataloader(self):
-        return self._loader(self.val_batches, self.val_max_durations, 2)
+        # the SAME clips at every validation: the monitored val_loss (ModelCheckpoint's top-k) compares like with like
+        return self._loader(self.val_batches, self.val_max_durations, 2, 0)

@@ -371,7 +371,7 @@ class VQGAN(nn.Module):
         return StreamingDecoder(self, batch, feature_lengths, return_audios, graph_chunk_tokens)
 
     @torch.no_grad()
-    def decode_stream(self, indices, feature_lengths=None, chunk_tokens: int = 64, noise: Optional[torch.Tensor] = None,
+    def decode_stream(self, indices, feature_lengths=None, *, chunk_tokens: int = 64, noise: Optional[torch.Tensor] = None,
                       return_audios: bool = True, use_graph: bool = False):
         """Generator: decode() fed `chunk_tokens` tokens at a time (indices: a (B, G, T4) tensor, or any iterable of (B, G, n) chunks),
         yielding (audio | None, gen_mel) pieces whose concatenation is BIT-identical to decode() on the whole sequence.  The decoder

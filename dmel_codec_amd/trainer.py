@@ -113,6 +113,16 @@ class ModelCheckpoint(Callback):
         if self.dirpath and self.save_last:
             self._save(trainer, model, os.path.join(self.dirpath, "last.ckpt"))
 
+    # Lightning stores this under checkpoint["callbacks"]: without it a resumed run starts with an empty top-k list, saves its first
+    # validation as "best" whatever its score and never prunes the files of the run it continues
+    def state_dict(self) -> dict:
+        return {"best": [list(b) for b in self.best], "last_saved_step": self._last_saved_step, "monitor": self.monitor, "mode": self.mode}
+
+    def load_state_dict(self, state: dict) -> None:
+        if state.get("monitor") == self.monitor and state.get("mode") == self.mode:
+            self.best = sorted((float(k), str(p)) for k, p in state.get("best", []) if os.path.exists(str(p)))
+        self._last_saved_step = int(state.get("last_saved_step", -1))
+
 
 class Trainer:
     def __init__(self, accelerator: str = "gpu", devices: Any = -1, precision: Any = 32, max_steps: int = -1,
@@ -183,7 +193,12 @@ class Trainer:
             "state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
             "optimizer_states": [o.state_dict() for o in model.optimizers()],
             "lr_schedulers": [s.state_dict() for s in model.lr_schedulers()],
-            "dmel_codec_amd": {"format": "lightning-layout", "version": 1},
+            "dmel_codec_amd": {"format": "lightning-layout", "version": 2},
+            # callback state (top-k list) and the generators the decoder's Gaussian input and the data order are drawn from: a resumed run
+            # continues the noise stream instead of restarting it
+            "callbacks": {f"{type(cb).__name__}#{i}": cb.state_dict() for i, cb in enumerate(self.callbacks) if hasattr(cb, "state_dict")},
+            "rng": {"torch": torch.get_rng_state(),
+                    "cuda": (torch.cuda.get_rng_state(self.device) if self.device.type == "cuda" else None)},
         }
         if hasattr(model, "on_save_checkpoint"):
             model.on_save_checkpoint(checkpoint)
@@ -211,6 +226,16 @@ class Trainer:
         self.current_epoch = int(checkpoint.get("epoch", 0))
         self.batches_seen = int(checkpoint.get("batches_seen", self.global_step // 2))
         self.batch_in_epoch = int(checkpoint.get("batch_in_epoch", 0))
+        saved = checkpoint.get("callbacks", {})
+        for i, cb in enumerate(self.callbacks):
+            st = saved.get(f"{type(cb).__name__}#{i}")
+            if st is not None and hasattr(cb, "load_state_dict"):
+                cb.load_state_dict(st)
+        rng = checkpoint.get("rng")
+        if rng:
+            torch.set_rng_state(rng["torch"])
+            if rng.get("cuda") is not None and self.device.type == "cuda":
+                torch.cuda.set_rng_state(rng["cuda"], self.device)
         if self.is_global_zero:
             print(f"[resume] {path}: epoch {self.current_epoch}, global_step {self.global_step} "
                   f"({len(missing)} keys not in the file, e.g. the vocoder's)", flush=True)
@@ -299,6 +324,9 @@ class Trainer:
                     if self.val_check_interval and self.batches_seen % int(self.val_check_interval) == 0:
                         self.validate(model, datamodule)
                 else:
+                    if self.batch_in_epoch == 0:
+                        # not one batch in a whole epoch: with max_steps = -1 and no max_epochs this loop would spin forever
+                        raise RuntimeError(f"epoch {self.current_epoch}: the training dataloader yielded no batch")
                     self.current_epoch += 1
                     self.batch_in_epoch = 0
                     continue

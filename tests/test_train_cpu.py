@@ -134,8 +134,25 @@ def test_trainer_counts_optimizer_steps_checkpoints_and_resumes(tmp_path):
     time.sleep(0.05)
     os.utime(tmp_path / "ckpt" / "last.ckpt")
     assert find_lastest_ckpt(str(tmp_path / "ckpt")).endswith("last.ckpt")
-    tr2, model2 = _fit(tmp_path, max_steps=20, seed=123)                                 # different init: must be overwritten by the file
+    assert ckpt["callbacks"]["ModelCheckpoint#0"]["best"] and "torch" in ckpt["rng"]     # callback state and generators travel with the file
+    best_before = [tuple(b) for b in ckpt["callbacks"]["ModelCheckpoint#0"]["best"]]
+    rng_probe = {}
+    orig_set = torch.set_rng_state
+
+    def spy(state):
+        rng_probe["restored"] = bool(torch.equal(state, ckpt["rng"]["torch"]))
+        return orig_set(state)
+    torch.set_rng_state = spy
+    try:
+        tr2, model2 = _fit(tmp_path, max_steps=20, seed=123)                             # different init: must be overwritten by the file
+    finally:
+        torch.set_rng_state = orig_set
+    assert rng_probe.get("restored") is True                                              # the noise stream continues where the file left it
     assert tr2.global_step == 20 and tr2.history[0]["step"] == 14
+    ck2 = [c for c in tr2.callbacks if type(c).__name__ == "ModelCheckpoint"][0]
+    # the resumed run knew the best score of the run it continues: at most one best file, and never a worse one than before
+    assert len(ck2.best) == 1 and ck2.best[0][0] <= best_before[0][0]
+    assert sum(1 for f in os.listdir(tmp_path / "ckpt") if f.startswith("epoch=")) <= 2     # the periodic file + the best one
     # the same 10 batches in one go give the same weights: resume is exact (same data order, optimiser and scheduler state)
     import shutil
     shutil.rmtree(tmp_path / "ckpt")
@@ -189,3 +206,21 @@ def test_launcher_counts_devices_without_touching_torch_cuda(monkeypatch, tmp_pa
     monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "1")
     assert bench.visible_gpu_count() == 1
     assert bench.spawn_ranks(2, [], script="/nonexistent") == 2      # too few devices: refused before anything is started
+
+
+def test_validation_clips_do_not_change_with_the_epoch_and_an_empty_epoch_raises(tmp_path):
+    from dmel_codec.dataset.synthetic import SyntheticDataModule
+    from dmel_codec_amd.trainer import Trainer
+    dm = SyntheticDataModule(sample_rate=100, train_max_durations=4.0, val_max_durations=2.0, train_batches_per_epoch=2, val_batches=2)
+    dm.set_epoch(0)
+    v0 = [b["audios"].clone() for b in dm.val_dataloader()]
+    t0 = [b["audios"].clone() for b in dm.train_dataloader()]
+    dm.set_epoch(3)
+    v3 = [b["audios"] for b in dm.val_dataloader()]
+    t3 = [b["audios"] for b in dm.train_dataloader()]
+    assert all(torch.equal(a, b) for a, b in zip(v0, v3))                  # val_loss of different epochs is measured on the same clips
+    assert not all(a.shape == b.shape and torch.equal(a, b) for a, b in zip(t0, t3))
+    empty = SyntheticDataModule(sample_rate=100, train_max_durations=4.0, val_max_durations=2.0, train_batches_per_epoch=0, val_batches=1)
+    tr = Trainer(accelerator="cpu", max_steps=-1, max_epochs=None, callbacks=[], logger=None)
+    with pytest.raises(RuntimeError, match="yielded no batch"):
+        tr.fit(ToyCodec(), empty)
