@@ -194,7 +194,11 @@ __device__ __forceinline__ void wg_split_store(const float (&v)[8], uint4* plane
 // staged step.  <1, 1, 64>: the fp32 kernel's tile (default).  <2, 2, 32>: 128 x 128, twice the flops per byte moved from L2 (opt-in).
 // grid (ceil(Cin / (64 NT)), ceil(Cout / (64 MT)), taps * slices); a.chunks_per_item counts KS-sample steps.
 // NP = 3: split fp32 (exact products); NP = 1: operands rounded to bf16 (round to nearest even), one MFMA per block -- the bf16 training mode
-template <int XS, int MT, int NT, int KS, int NP = 3>
+// FLAT (round 3): the reduction runs over the flattened sample index n = b * T + t in steps of KS, as conv_wgrad_kernel<2> does, for rows of
+// 33..255 samples (the 92-frame WaveNet GEMMs ran on the fp32 MFMA at its peak, 158 TF/s: the matrix pipe itself was the limit).  Every
+// step takes the clamped scalar loads of the boundary path, with the item index carried per element (a group of 8 samples crosses at
+// most one item boundary because T > 8).
+template <int XS, int MT, int NT, int KS, int NP = 3, bool FLAT = false>
 __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
   constexpr int UR = KS / 8 + 1;                                 // uint4 units per LDS row incl. one pad unit: conflict-free 128-bit reads
   constexpr int RM = 64 * MT, RN = 64 * NT;                      // staged rows of dy / x
@@ -232,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
     x_mul = kF16XScale;
     out_mul = __uint_as_float((uint32_t)(127 - 13 + e) << 23) * (1.f / kF16XScale);
   }
-  const int total = a.B * a.chunks_per_item;
+  const int total = FLAT ? (a.B * a.T + KS - 1) / KS : a.B * a.chunks_per_item;
   const int c_begin = slice * a.chunks_per_slice, c_end = min(total, c_begin + a.chunks_per_slice);
   const int r31 = lane & 31, hh = lane >> 5;
   const int srow = tid / G, sg = tid % G;                        // staging: row within a pass, group of 8 samples
@@ -243,6 +247,41 @@ __global__ __launch_bounds__(256) void conv_wgrad_split_kernel(WgArgs a) {
   unsigned md[2][PD], mx[2][PX];
   auto fetch = [&](auto set, int c) {
     constexpr int S = decltype(set)::value;
+    if constexpr (FLAT) {
+      const int n0 = c * KS + 8 * sg;
+      const int b0 = n0 / a.T, t0f = n0 - b0 * a.T;
+      int64_t offd[8], offx[8];              // element offsets without the row term
+      unsigned okd = 0, okx = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        int te = t0f + e, be = b0;
+        if (te >= a.T) { te -= a.T; be += 1; }
+        const bool ok = be < a.B;
+        const int bc = min(be, a.B - 1);
+        const int tx = te * XS + a.xoff + shift;
+        offd[e] = (int64_t)bc * a.Cout * a.T + te;
+        offx[e] = (int64_t)bc * a.Cin * a.Tx + min(max(tx, 0), a.Tx - 1);
+        okd |= (unsigned)ok << e;
+        okx |= (unsigned)(ok && tx >= 0 && tx < a.Tx) << e;
+      }
+#pragma unroll
+      for (int ps = 0; ps < PD; ++ps) {
+        const int co = co0 + srow + RP * ps;
+        const float* p = a.dy + (int64_t)min(co, a.Cout - 1) * a.T;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rd[S][ps][e] = p[offd[e]];
+        md[S][ps] = co < a.Cout ? okd : 0u;
+      }
+#pragma unroll
+      for (int ps = 0; ps < PX; ++ps) {
+        const int ci = ci0 + srow + RP * ps;
+        const float* q = a.x + (int64_t)min(ci, a.Cin - 1) * a.Tx;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rx[S][ps][e] = q[offx[e]];
+        mx[S][ps] = ci < a.Cin ? okx : 0u;
+      }
+      return;
+    }
     const int b = c / a.chunks_per_item;
     const int t0 = (c - b * a.chunks_per_item) * KS;
     const int t = t0 + 8 * sg;
@@ -618,7 +657,19 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   const bool split = a.ipc == 1 && !wgrad_native_only() && a.xstride <= 2 && a.T >= 256;
   // the three-tap kernel also serves the bf16 training mode (its fp16 split is more accurate than bf16 operands and, without atomics, faster)
   const bool can_group = split && a.dil == 1 && a.taps % 3 == 0;
-  if (split && (train_precision_override() != DMEL_PRECISION_BF16 || can_group)) {
+  // rows of 33..255 samples whose last 64-sample step would be mostly padding (T = 92: 30 % of the MFMA work) reduce over the flattened
+  // index; in fp32 training mode on the fp16-split kernel (FLAT instantiation), which needs the launch's max |dy| like the long rows do
+  static const bool flat_off = [] { const char* e = getenv("DMEL_WGRAD_NOFLAT"); return e != nullptr; }();
+  // measured (round 3, tools/bench_train_step.py): weight-gradient time per step 25.8 -> 30.5 ms with the FLAT fp16-split instantiation --
+  // its staging (scalar loads with per-element item indices, masks, scale, split, pack: ~500 vector instructions per 64-sample step and
+  // wave) costs what the 32 fp32 MFMAs it replaces cost (2048 cycles), plus one absmax launch per gradient tensor.  Opt-in, for A/B.
+  static const bool flat16_off = [] { const char* e = getenv("DMEL_WGRAD_FLAT16"); return !(e && e[0] == '1'); }();
+  static const bool f16_off0 = [] { const char* e = getenv("DMEL_WGRAD_F16X2"); return e && e[0] == '0'; }();
+  const bool flat_shape = !split && a.ipc == 1 && a.T < 256 && (int64_t)a.B * a.T < ((int64_t)1 << 30) &&
+                          ((a.T + kWgK - 1) / kWgK) * kWgK * 10 > a.T * 11 && !flat_off;
+  const bool flat16 = flat_shape && a.T >= 33 && a.xstride <= 2 && !wgrad_native_only() && !flat16_off && !f16_off0 &&
+                      train_precision_override() != DMEL_PRECISION_BF16;
+  if ((split && (train_precision_override() != DMEL_PRECISION_BF16 || can_group)) || flat16) {
     if (!a.dy_absmax) DMEL_TRY(launch_absmax(a.dy, (int64_t)a.B * a.Cout * a.T, st, &a.dy_absmax));
   } else {
     a.dy_absmax = nullptr;
@@ -674,9 +725,7 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.chunks_per_item = (a.T + ks - 1) / ks;
   const int tm = (a.Cout + tile - 1) / tile, tn = (a.Cin + tile - 1) / tile;
   const int tiles = tm * tn * a.taps;
-  // rows of 33..255 samples whose last 64-sample step would be mostly padding (T = 92: 30 % of the MFMA work) reduce over the flattened index
-  const bool flat = !split && a.ipc == 1 && a.T < 256 && (int64_t)a.B * a.T < ((int64_t)1 << 30) &&
-                    a.chunks_per_item * kWgK * 10 > a.T * 11 && !getenv("DMEL_WGRAD_NOFLAT");
+  const bool flat = flat_shape;
   const int total = a.ipc > 1 ? (a.B + a.ipc - 1) / a.ipc : flat ? (a.B * a.T + kWgK - 1) / kWgK : a.B * a.chunks_per_item;
   // enough K slices to fill the chip (~8 workgroups of the small tile / ~4 of the large one per CU), each at least 8 staged steps long
   const char* we2 = getenv("DMEL_WGRAD_WANT");
@@ -687,6 +736,8 @@ static int launch_wgrad_any(WgArgs a, hipStream_t st) {
   a.chunks_per_slice = (total + slices - 1) / slices;
   const dim3 grid((unsigned)tn, (unsigned)tm, (unsigned)(a.taps * slices));
   if (a.ipc > 1) hipLaunchKernelGGL(conv_wgrad_kernel<1>, grid, dim3(256), 0, st, a);
+  else if (flat16 && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 1, 1, 64, 2, true>), grid, dim3(256), 0, st, a);
+  else if (flat16) hipLaunchKernelGGL((conv_wgrad_split_kernel<2, 1, 1, 64, 2, true>), grid, dim3(256), 0, st, a);
   else if (flat) hipLaunchKernelGGL(conv_wgrad_kernel<2>, grid, dim3(256), 0, st, a);
   else if (!split) hipLaunchKernelGGL(conv_wgrad_kernel<0>, grid, dim3(256), 0, st, a);
   else if (big && a.xstride == 1) hipLaunchKernelGGL((conv_wgrad_split_kernel<1, 2, 2, 32>), grid, dim3(256), 0, st, a);
