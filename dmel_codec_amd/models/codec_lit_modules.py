@@ -260,8 +260,8 @@ class VQGAN(nn.Module):
     def validation_step(self, batch, batch_idx, noise: Optional[torch.Tensor] = None):
         """codec_lit_modules.py:330-396: masked L1 between the re-synthesised and the ground-truth mel with the quality input fixed at 2
         (the condition is not masked again here, :373-379), logged as "val_loss"; then the vocoder on both mels.  The reference hands
-        figures and audio of the first sample to its logger (:398-460) and returns nothing; the mirror has no logger, so it returns the
-        tensors a caller would log.  `noise` (extension) injects the decoder's Gaussian input."""
+        figures and audio of the first sample to its logger (:398-460) and returns nothing; the mirror returns the tensors and
+        `Trainer.validate` hands the first sample of the first four batches to the logger (`JsonlLogger.log_validation_sample`).  `noise` (extension) injects the decoder's Gaussian input."""
         if self.decoder is None:
             raise ValueError("Decoder is not loaded")
         audios, audio_lengths = batch["audios"], batch["audio_lengths"]

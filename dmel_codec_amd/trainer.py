@@ -58,6 +58,37 @@ class JsonlLogger:
         self._f.write(json.dumps({"step": step, **{k: float(v) for k, v in metrics.items()}}) + "\n")
         self._f.flush()
 
+    def log_validation_sample(self, tag: str, gt_mel, gen_mel, wavs: dict, sample_rate: int, step: int) -> str:
+        """What the reference hands to TensorBoard for the first sample of the first validation batches (codec_lit_modules.py:398-460):
+        a figure of the ground-truth and the re-synthesised mel and three waveforms (gt / gen / recon).  Here: files under
+        save_dir/name/samples/step=<step>/<tag>/ -- mels.png (matplotlib, Agg) or mels.npy, and 16-bit PCM <key>.wav."""
+        import wave
+        import numpy as np
+        d = os.path.join(self.dir, "samples", f"step={step:06d}", tag)
+        os.makedirs(d, exist_ok=True)
+        gt, gen = gt_mel.detach().float().cpu().numpy(), gen_mel.detach().float().cpu().numpy()
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+            fig, axes = plt.subplots(2, 1, figsize=(10, 6), squeeze=False)          # utils/utils.py plot_mel: one panel per mel, titled
+            for ax, m, title in zip(axes[:, 0], (gt, gen), ("Ground-Truth", "Auxiliary")):
+                ax.imshow(m, origin="lower", aspect="auto")
+                ax.set_title(title, fontsize="medium")
+                ax.tick_params(labelsize="x-small", left=False, labelleft=False)
+            fig.savefig(os.path.join(d, "mels.png"), dpi=80)
+            plt.close(fig)
+        except Exception:
+            np.save(os.path.join(d, "mels.npy"), np.stack([gt, gen]))
+        for key, w in wavs.items():
+            pcm = (w.detach().float().cpu().clamp(-1, 1).numpy().reshape(-1) * 32767.0).astype("<i2")
+            with wave.open(os.path.join(d, f"{key}.wav"), "wb") as f:
+                f.setnchannels(1)
+                f.setsampwidth(2)
+                f.setframerate(int(sample_rate))
+                f.writeframes(pcm.tobytes())
+        return d
+
 
 class ModelCheckpoint(Callback):
     """lightning.pytorch.callbacks.ModelCheckpoint for the arguments the codec configs pass (dMel_example.yaml:135-144): a
@@ -254,8 +285,18 @@ class Trainer:
         for i, batch in enumerate(datamodule.val_dataloader()):
             if self.limit_val_batches is not None and i >= self.limit_val_batches:
                 break
-            out = model.validation_step(self._to_device(batch), i)
+            dev_batch = self._to_device(batch)
+            out = model.validation_step(dev_batch, i)
             n = batch["audios"].shape[0]
+            # codec_lit_modules.py:398-460: figures and audio of the FIRST sample of the first four batches go to the logger
+            if i < 4 and self.is_global_zero and hasattr(self.logger, "log_validation_sample") and "gen_aux_mels" in out:
+                alen = int(torch.as_tensor(batch["audio_lengths"]).reshape(-1)[0])
+                hop = getattr(getattr(model, "gt_mel_transform", None) or getattr(model, "encode_mel_transform", None), "hop_length", 256)
+                ml = max(1, alen // hop)
+                self.logger.log_validation_sample(
+                    f"sample-{i}-0", out["gt_mels"][0, :, :ml], out["gen_aux_mels"][0, :, :ml],
+                    {"gt": dev_batch["audios"][0, 0, :alen], "gen": out["gen_aux_audios"][0, 0, :alen], "recon": out["recon_audios"][0, 0, :alen]},
+                    getattr(model, "sampling_rate", 24000), self.global_step)
             total += float(out["val_loss"]) * n
             count += n
         stats = torch.tensor([total, float(count)], dtype=torch.float64, device=self.device)

@@ -408,6 +408,12 @@ def test_train_codec_under_torch_distributed_run_two_ranks(dev, tmp_path):
     assert ckpt["global_step"] == 8 and not any("vocoder" in k for k in ckpt["state_dict"])
     lines = [l for l in open(tmp_path / "tb" / "dmel_codec_20hz" / "metrics.jsonl")]
     assert any("val_loss" in l for l in lines)
+    # the first validation sample's figure and audio (codec_lit_modules.py:398-460), written by rank 0 only
+    samples = tmp_path / "tb" / "dmel_codec_20hz" / "samples"
+    steps = sorted(os.listdir(samples))
+    assert steps and steps[0].startswith("step=")
+    got = sorted(os.listdir(samples / steps[0] / "sample-0-0"))
+    assert {"gt.wav", "gen.wav", "recon.wav"} <= set(got) and ("mels.png" in got or "mels.npy" in got), got
 
 
 # ------------------------------------------------------------------------------------ data front end and MR-STFT loss

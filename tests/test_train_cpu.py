@@ -224,3 +224,17 @@ def test_validation_clips_do_not_change_with_the_epoch_and_an_empty_epoch_raises
     tr = Trainer(accelerator="cpu", max_steps=-1, max_epochs=None, callbacks=[], logger=None)
     with pytest.raises(RuntimeError, match="yielded no batch"):
         tr.fit(ToyCodec(), empty)
+
+
+def test_logger_writes_the_validation_sample_the_reference_hands_to_tensorboard(tmp_path):
+    """codec_lit_modules.py:398-460: mel figure + gt / gen / recon audio of the first sample -> files under the logger's directory."""
+    import wave
+    from dmel_codec_amd.trainer import JsonlLogger
+    lg = JsonlLogger(str(tmp_path), "run")
+    d = lg.log_validation_sample("sample-0-0", torch.randn(80, 50), torch.randn(80, 50),
+                                 {"gt": torch.randn(12800) * 0.1, "gen": torch.randn(12800) * 0.1, "recon": 3 * torch.randn(12800)}, 24000, 12)
+    assert d.endswith(os.path.join("samples", "step=000012", "sample-0-0"))
+    got = set(os.listdir(d))
+    assert {"gt.wav", "gen.wav", "recon.wav"} <= got and ("mels.png" in got or "mels.npy" in got)
+    with wave.open(os.path.join(d, "recon.wav")) as w:
+        assert w.getframerate() == 24000 and w.getnframes() == 12800 and w.getsampwidth() == 2      # clipped to [-1, 1], 16-bit PCM
