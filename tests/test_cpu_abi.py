@@ -281,3 +281,15 @@ def test_copies_of_a_mirror_never_share_its_native_handle():
         assert copy.deepcopy(s).spectrogram._plan is None
     finally:
         s.spectrogram._plan = None
+
+
+def test_lanes_refuse_a_cpu_codec():
+    """dmel_codec_amd.pipeline.CodecLanes has no CPU form either: a codec that is not on a GPU raises (it would otherwise copy the codec
+    and fail later, inside the first native call)."""
+    from dmel_codec_amd.configs import build_codec
+    from dmel_codec_amd.pipeline import CodecLanes
+    codec = build_codec(n_mels=80, dmel_groups=8, encoder_layers=1, decoder_layers=1, vocoder=None)
+    with pytest.raises(RuntimeError, match="CUDA"):
+        CodecLanes(codec, 2)
+    with pytest.raises(ValueError):
+        CodecLanes(codec, 0)
