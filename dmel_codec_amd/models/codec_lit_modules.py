@@ -363,22 +363,26 @@ class VQGAN(nn.Module):
 
     # ------------------------------------------------------------------------------ streaming decode (extension)
     def streaming_decoder(self, batch: int = 1, feature_lengths: Optional[torch.Tensor] = None, return_audios: bool = True,
-                          graph_chunk_tokens: Optional[int] = None):
+                          graph_chunk_tokens: Optional[int] = None, overlap_vocoder: bool = False):
         """Incremental decode with state carry (the reference decodes once, after the LM has finished,
         lm_lit_modules.py:467-471): feed token chunks as they arrive with .push(ids (B, G, n)), get audio back as soon as its right
         context exists; .finish() flushes.  See StreamingDecoder.  graph_chunk_tokens = n: once the stream has reached its steady state, a
-        push of exactly n tokens is ONE HIP-graph replay instead of ~250 launches (an unbounded stream: feature_lengths must be None)."""
-        return StreamingDecoder(self, batch, feature_lengths, return_audios, graph_chunk_tokens)
+        push of exactly n tokens is ONE HIP-graph replay instead of ~250 launches (an unbounded stream: feature_lengths must be None).
+        overlap_vocoder: the vocoder of a push runs on its own stream (StreamingDecoder.wait_audio before the audio is used)."""
+        return StreamingDecoder(self, batch, feature_lengths, return_audios, graph_chunk_tokens, overlap_vocoder)
 
     @torch.no_grad()
     def decode_stream(self, indices, feature_lengths=None, *, chunk_tokens: int = 64, noise: Optional[torch.Tensor] = None,
-                      return_audios: bool = True, use_graph: bool = False):
+                      return_audios: bool = True, use_graph: bool = False, pipeline: bool = False):
         """Generator: decode() fed `chunk_tokens` tokens at a time (indices: a (B, G, T4) tensor, or any iterable of (B, G, n) chunks),
         yielding (audio | None, gen_mel) pieces whose concatenation is BIT-identical to decode() on the whole sequence.  The decoder
         WaveNet keeps the output history of every block and only ever computes new columns (dmel_wavenet_stream_step: total work 1.0x);
         the quantiser and the vocoder -- receptive fields of 3 and ~20 frames -- run on the new frames plus that context and are
         cropped.  A piece is emitted once its right context (WaveNet 75 + vocoder ~20 frames) has arrived.
-        noise: (B, C, 4 T4) for reproducible runs (tensor input only), else drawn per chunk like decode() draws it."""
+        noise: (B, C, 4 T4) for reproducible runs (tensor input only), else drawn per chunk like decode() draws it.
+        pipeline=True: the vocoder runs on its own stream and a piece is yielded one chunk LATER -- after the next chunk has been pulled from
+        `indices` and pushed -- so that the vocoder of chunk i overlaps the decoder WaveNet of chunk i + 1 (same pieces, same bits; an
+        iterator that blocks until the LM has produced the next chunk delays every piece by that long)."""
         if torch.is_tensor(indices):
             T4 = indices.shape[2]
             chunks = (indices[:, :, a:a + chunk_tokens] for a in range(0, T4, chunk_tokens))
@@ -389,19 +393,34 @@ class VQGAN(nn.Module):
             batch = first.shape[0]
             import itertools
             chunks = itertools.chain([first], chunks)
-        dec = self.streaming_decoder(batch, feature_lengths, return_audios, graph_chunk_tokens=chunk_tokens if use_graph else None)
+        dec = self.streaming_decoder(batch, feature_lengths, return_audios, graph_chunk_tokens=chunk_tokens if use_graph else None,
+                                     overlap_vocoder=pipeline and return_audios)
         factor = math.prod(self.quantizer.downsample_factor)
         pos = 0
+        held = None                                   # pipeline: (piece, its vocoder's event), yielded after the NEXT push was enqueued
+
+        def release(h):
+            (audio, mel), ev = h
+            return dec.wait_audio(audio, ev), mel
+
         for ids in chunks:
             n = ids.shape[2]
             nz = noise[:, :, pos * factor:(pos + n) * factor] if noise is not None else None
             pos += n
             out = dec.push(ids, noise=nz)
-            if out[1].shape[-1]:
+            if pipeline and return_audios:
+                if held is not None:
+                    yield release(held)
+                    held = None
+                if out[1].shape[-1]:
+                    held = (out, dec.audio_event)
+            elif out[1].shape[-1]:
                 yield out
         out = dec.finish()
+        if held is not None:
+            yield release(held)
         if out[1].shape[-1]:
-            yield out
+            yield (dec.wait_audio(out[0]), out[1]) if pipeline and return_audios else out
 
     #: mel frames of context the decode path needs on each side of a chunk for its interior to be exact:
     #: conditional WaveNet 20 layers x dilations (1,2,4,8) = 75, BigVGAN-base ~19 (conv_pre 3 + AMP/snake halos of the
@@ -461,9 +480,12 @@ class StreamingDecoder:
 
     QUANT_HALO_TOKENS = 4        # ConvNeXt k7 at rates 2 and 4: 3 / 2 + 3 / 4 tokens of context on each side
 
-    def __init__(self, codec: VQGAN, batch: int, feature_lengths, return_audios: bool, graph_chunk_tokens: Optional[int] = None):
+    def __init__(self, codec: VQGAN, batch: int, feature_lengths, return_audios: bool, graph_chunk_tokens: Optional[int] = None,
+                 overlap_vocoder: bool = False):
         if codec.decoder is None:
             raise ValueError("Decoder is not loaded")
+        if overlap_vocoder and graph_chunk_tokens is not None:
+            raise ValueError("overlap_vocoder and graph_chunk_tokens exclude each other: a replayed graph is one unit on its launch stream")
         if graph_chunk_tokens is not None and feature_lengths is not None:
             raise ValueError("graph_chunk_tokens needs an unbounded stream (feature_lengths=None): length masks change from push to push")
         if return_audios and codec.vocoder is None:
@@ -495,6 +517,13 @@ class StreamingDecoder:
         # its time is launch count, not arithmetic.  In the steady state every push of n tokens does the same work at the same offsets
         # RELATIVE to the buffers' origin; with the buffers re-based at the start of every push those offsets are also the same
         # ADDRESSES, and the whole push -- quantiser window, every WaveNet block's new columns, vocoder window -- is one graph.
+        # overlap_vocoder: the vocoder of a push runs on a stream of its own.  Within one stream the decoder WaveNet of chunk i + 1 does
+        # not depend on the vocoder of chunk i (only on the WaveNet's own history), so a caller that pushes chunk i + 1 BEFORE consuming
+        # the audio of chunk i (VQGAN.decode_stream(pipeline=True) does) has the two running side by side: a push costs
+        # max(WaveNet, vocoder) instead of their sum.  The audio returned by push() is then valid after `wait_audio()`.
+        self._overlap = bool(overlap_vocoder) and return_audios
+        self._voc_stream = None
+        self.audio_event = None
         self._g_n = int(graph_chunk_tokens) if graph_chunk_tokens else None
         self._rebase = self._g_n is not None      # always move the origin to the oldest column still needed (constant layout)
         self._graph = None
@@ -670,7 +699,19 @@ class StreamingDecoder:
             if e_new > self.emitted:
                 lo = max(0, self.emitted - self.voc_halo)
                 hi = min(ready, e_new + self.voc_halo)
-                wav = codec.vocoder(self.buf["mel"][:, :, lo - o:hi - o].contiguous())
+                win = self.buf["mel"][:, :, lo - o:hi - o].contiguous()
+                if self._overlap:
+                    cur = torch.cuda.current_stream(dev)
+                    if self._voc_stream is None:
+                        self._voc_stream = torch.cuda.Stream(device=dev)
+                    self._voc_stream.wait_stream(cur)               # the window copy above (and everything before it) is done
+                    with torch.cuda.stream(self._voc_stream):
+                        wav = codec.vocoder(win)
+                        self.audio_event = torch.cuda.Event()
+                        self.audio_event.record(self._voc_stream)
+                    win.record_stream(self._voc_stream)
+                else:
+                    wav = codec.vocoder(win)
                 audio = wav[:, :, (self.emitted - lo) * self.up:(e_new - lo) * self.up]
             else:
                 audio = torch.empty(self.B, 1, 0, dtype=torch.float32, device=dev)
@@ -678,6 +719,17 @@ class StreamingDecoder:
         if final:
             self.finished = True
         return audio, mel
+
+    def wait_audio(self, audio: Optional[torch.Tensor] = None, event: Optional["torch.cuda.Event"] = None):
+        """overlap_vocoder: make the current stream wait for the vocoder of the last push (or of `event`, as saved from `audio_event`
+        right after a push) and return `audio`, now safe to use on this stream.  No host synchronisation."""
+        ev = event if event is not None else self.audio_event
+        if ev is not None:
+            cur = torch.cuda.current_stream()
+            cur.wait_event(ev)
+            if audio is not None and audio.numel():
+                audio.record_stream(cur)
+        return audio
 
     def finish(self):
         """no more tokens: flush everything that was waiting for right context"""

@@ -696,6 +696,16 @@ def test_incremental_decode_with_state_carry(dev, pattern):
     assert sum(p[1].shape[-1] for p in parts) == T4 * 4 and all(p[0] is None for p in parts)
     mel_g = torch.cat([p[1] for p in codec.decode_stream(ids, flen, chunk_tokens=50, noise=noise, return_audios=False)], dim=-1)
     assert torch.equal(mel_g, mel)
+    # pipeline=True: the vocoder of chunk i on its own stream under the WaveNet of chunk i + 1, pieces one chunk later -- same pieces, same bits
+    if pattern == "64":
+        plain = list(codec.decode_stream(ids, flen, chunk_tokens=40, noise=noise))
+        piped = list(codec.decode_stream(ids, flen, chunk_tokens=40, noise=noise, pipeline=True))
+        assert len(plain) == len(piped)
+        for (a0, m0), (a1, m1) in zip(plain, piped):
+            assert torch.equal(a0, a1) and torch.equal(m0, m1)
+        assert torch.equal(torch.cat([p[0] for p in piped], dim=-1), audio)
+        with pytest.raises(ValueError, match="exclude"):
+            codec.streaming_decoder(B, None, True, graph_chunk_tokens=32, overlap_vocoder=True)
 
 
 def test_lanes_match_sequential(dev):

@@ -12,6 +12,35 @@ g = torch.Generator().manual_seed(5)
 T4 = 469                                      # 20 s of audio at 23.4 token frames per second
 ids = torch.randint(0, 175, (1, 10, T4), generator=g, dtype=torch.int32).to(dev)
 flen = torch.tensor([T4], device=dev)
+ONLY_PIPE = "--pipeline-only" in sys.argv
+
+
+def pipeline_section():
+    # decode_stream(pipeline=True): the vocoder of chunk i on its own stream, overlapping the decoder WaveNet of chunk i + 1 (pieces are
+    # yielded one chunk later); 120 s stream, batch 1 and 16, against the sequential generator
+    T4L = 2813
+    gl = torch.Generator().manual_seed(6)
+    ids_long = torch.randint(0, 175, (1, 10, T4L), generator=gl, dtype=torch.int32).to(dev)
+    for B in (1, 16):
+        ids_b = ids_long.expand(B, -1, -1).contiguous()
+        for chunk in (32, 64, 128):
+            for pipe in (False, True):
+                for rep in range(2):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    n = 0
+                    for a, m in codec.decode_stream(ids_b, None, chunk_tokens=chunk, pipeline=pipe):
+                        n += a.shape[-1]
+                    torch.cuda.synchronize()
+                    el = time.perf_counter() - t0
+                print(json.dumps({"mode": "decode_stream pipeline" if pipe else "decode_stream", "batch": B, "chunk_tokens": chunk,
+                                  "audio_s_per_stream": round(n / 24000, 2), "ms_per_chunk": round(el * 1e3 / ((T4L + chunk - 1) // chunk), 3),
+                                  "audio_sec_per_sec_all_streams": round(B * n / 24000 / el, 1)}), flush=True)
+
+
+if ONLY_PIPE:
+    pipeline_section()
+    sys.exit(0)
 for chunk in (8, 32, 64, 128):
     list(codec.decode_stream(ids, flen, chunk_tokens=chunk))      # warm-up (handles, workspaces)
     torch.cuda.synchronize()
@@ -81,3 +110,4 @@ t0 = time.perf_counter()
 a, _ = codec.decode(ids, flen, return_audios=True)
 torch.cuda.synchronize()
 print(json.dumps({"whole_sequence_decode_ms": round((time.perf_counter() - t0) * 1e3, 2), "audio_s": round(a.shape[-1] / 24000, 2)}))
+pipeline_section()
