@@ -645,9 +645,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   //         by the barrier that opened this chunk), so the barrier closing the chunk has only MFMAs in front of it.
   // (Register double-buffering of the x fragments was tried and dropped: the ds_read latency hides behind the other wave.)
   constexpr int kWLoads = MT * NP;                                              // weight loads per step and wave
-  constexpr int kWaitW = (kWLoads & 15) | (7 << 4) | (15 << 8) | ((kWLoads >> 4) << 14);   // s_waitcnt vmcnt(kWLoads)
+  // at the end of step s only the weights of step s + 1 have to be home: the loads of steps s + 2 .. s + PD stay in flight.  (Until round 3
+  // the wait was vmcnt(kWLoads) whatever PD: a prefetch distance above 2 then fetched earlier but was drained just the same -- the
+  // "PD = 3" experiment of profiles/r03_conv_experiments.txt measured nothing.)
+  constexpr int kWKeep = (PD - 1) * kWLoads < 63 ? (PD - 1) * kWLoads : 63;
+  constexpr int kWaitW = (kWKeep & 15) | (7 << 4) | (15 << 8) | ((kWKeep >> 4) << 14);     // s_waitcnt vmcnt((PD - 1) kWLoads)
   constexpr int kXLoads = NIT * (PS != 0 ? 2 : 8);                                          // x loads per thread and chunk
-  constexpr int kWX = kWLoads + kXLoads < 63 ? kWLoads + kXLoads : 63;
+  constexpr int kWX = kWKeep + kXLoads < 63 ? kWKeep + kXLoads : 63;
   [[maybe_unused]] constexpr int kWaitWX = (kWX & 15) | (7 << 4) | (15 << 8) | ((kWX >> 4) << 14);           // ... that also leaves a chunk of x loads in flight
 #if DMEL_BPF
   bf16x8 bfrag[2][NT][NP];
