@@ -833,15 +833,28 @@ template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int til
 // length (bv2, 128 rows x 5888 columns: 176 / 233 / 250 TF/s against 117 / 182 / 206).
 // Within NP = 2 (MI355X, tools/bench_conv.py --precision 3): 256-row problems with long rows gain 5-8 % from the eight-wave 256 x 96 tile (x is
 // converted once per 256 rows); 128-row problems with >= 40 K steps gain 6-17 % from 128 x 64 (124 registers, four waves per SIMD).
-static int pick_tile_bf16(int mtiles, int64_t T, int np, int steps) {
+static int pick_tile_bf16(int mtiles, int64_t T, int np, int steps, int B) {
   const char* e = getenv("DMEL_CONV_TILE_BF16");        // per call: tools/ab_wavenet.py switches tiles inside one process
-  const int forced = e ? atoi(e) : -1;
+  const int forced = (e && e[0]) ? atoi(e) : -1;
   if (forced >= 0 && forced < 8) return forced;
-  if (np == 2 && mtiles >= 8 && T > 96) return 7;
-  if (np == 2 && mtiles >= 4 && mtiles < 8 && steps >= 40) return 6;
-  if (mtiles >= 4) return (T > 2048 && np != 2) ? 4 : 1;
-  if (mtiles >= 2) return 2;
-  return 3;
+  int t;
+  if (np == 2 && mtiles >= 8 && T > 96) t = 7;
+  else if (np == 2 && mtiles >= 4 && mtiles < 8 && steps >= 40) t = 6;
+  else if (mtiles >= 4) t = (T > 2048 && np != 2) ? 4 : 1;
+  else if (mtiles >= 2) t = 2;
+  else t = 3;
+  // FEW COLUMNS (streaming decode of one stream: 128-512 frames per push; round 3): when the choice above makes fewer workgroups than half
+  // the CUs -- 18 for the decoder WaveNet's gate convolution at a 64-token chunk -- the launch is a handful of long K loops on an idle
+  // chip.  The 128 x 64 tile (four waves) makes 2-3x as many.  Every tile accumulates K in the same order: same bits, so a streamed chunk
+  // still equals the whole-sequence decode (tests).  Measured (tools/bench_stream.py, batch 1, pipelined): 64-token chunks 480 -> 589
+  // audio-s/s, 128-token 877 -> 1025 (profiles/r03_stream.txt).
+  if (np == 2 && mtiles >= 4 && t != 6) {
+    static const int bm[8] = {128, 128, 64, 32, 128, 64, 128, 256}, bn[8] = {128, 96, 128, 256, 128, 128, 64, 96};
+    const int64_t wgs = (int64_t)((mtiles * 32 + bm[t] - 1) / bm[t]) * ((T + bn[t] - 1) / bn[t]) * B;
+    static const bool off = [] { const char* f = getenv("DMEL_CONV_SMALLN"); return f && f[0] == '0'; }();
+    if (wgs < 128 && !off) t = 6;
+  }
+  return t;
 }
 
 // Pre-split inputs (SegRun::xp; the decoder WaveNet's gate and residual / skip convolutions): the fp16-split kernel with a staging pass
@@ -862,7 +875,7 @@ template <int MODE> static int launch_presplit(const KArgs& ka, int B, int64_t T
 }
 
 template <int NP> static int launch_bf16_any(const KArgs& ka, EpiMode mode, int B, int64_t Tcols, hipStream_t st) {
-  const int t16 = pick_tile_bf16(ka.mtiles, Tcols, NP, ka.steps);
+  const int t16 = pick_tile_bf16(ka.mtiles, Tcols, NP, ka.steps, B);
   switch (mode) {
     case EPI_LINEAR: return launch_mode_bf16<EPI_LINEAR, NP>(ka, t16, B, st);
     case EPI_GATE: return launch_mode_bf16<EPI_GATE, NP>(ka, t16, B, st);
@@ -1008,7 +1021,7 @@ static int check_f16_range(const PackedConv& pc, const ConvRun& r, hipStream_t s
 int launch_conv(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
   {  // producer / consumer kernel for the launches it was measured to win on (conv_pc.hip); DMEL_CONV_PC=0 is the A/B switch, read per call
     const char* e = getenv("DMEL_CONV_PC");
-    if (!(e && e[0] == '0') && conv_pc_eligible(pc, r)) {
+    if (!(e && e[0] == '0') && conv_pc_eligible(pc, r, e && e[0] == '2')) {      // 2: also tiny launches (bit-identity tests on small shapes)
       DMEL_TRY(check_f16_range(pc, r, stream));
       return launch_conv_pc(pc, r, stream);
     }

@@ -230,7 +230,7 @@ static int launch_pc(const KArgs& ka, int B, hipStream_t st) {
   return DMEL_OK;
 }
 
-bool conv_pc_eligible(const PackedConv& pc, const ConvRun& r) {
+bool conv_pc_eligible(const PackedConv& pc, const ConvRun& r, bool any_size) {
   const PackDesc& d = pc.d;
   if (d.phases != 1 || r.out_tstride != 1 || r.phase_base != 0 || r.fold_pitch != 0 || r.row_scale || r.yp) return false;
   if (r.precision != DMEL_PRECISION_FP32_F16X2 || train_precision_override() == DMEL_PRECISION_BF16 || getenv("DMEL_CONV_FP32_MFMA")) return false;
@@ -245,11 +245,15 @@ bool conv_pc_eligible(const PackedConv& pc, const ConvRun& r) {
   if (halo > 64 || (halo > 16 && d.mode != EPI_LINEAR)) return false;       // the paired modes are built with the 16-column halo only
   if (halo == 0) return false;      // pointwise convolutions: a staged chunk is ONE K step here (a barrier per step); conv_bf16_kernel stages 32
                                     // channels per barrier for them and stays ahead (wn_dec_1x1: 43 vs 46 us)
+  // few columns (one stream of the streaming decoder): a 256 x 96 tile per workgroup leaves most CUs without one; conv_bf16_kernel's
+  // small-N tile choice (pick_tile_bf16) serves those launches
+  const int64_t wgs = (int64_t)((pc.Mpad + 255) / 256) * ((r.Tcols + 95) / 96) * r.B;
+  if (wgs < 128 && !any_size) return false;
   return pc.Mpad / 32 >= 5;                                                   // eight strips of 32 rows per workgroup: the layout that gains
 }
 
 int launch_conv_pc(const PackedConv& pc, const ConvRun& r, hipStream_t stream) {
-  DMEL_CHECK_ARG(conv_pc_eligible(pc, r), "conv_pc: this convolution is outside what the producer / consumer kernel is built for");
+  DMEL_CHECK_ARG(conv_pc_eligible(pc, r, true), "conv_pc: this convolution is outside what the producer / consumer kernel is built for");
   DMEL_CHECK_ARG(r.y && r.B > 0 && r.Tcols > 0, "conv_pc: bad output / shape");
   const PackDesc& d = pc.d;
   DMEL_CHECK_ARG(d.mode != EPI_RESSKIP || r.skip != nullptr, "conv_pc: skip buffer missing");

@@ -64,7 +64,7 @@ int launch_conv_snake(const PackedConv& pc, const ConvRun& r, const float* alpha
 // Producer / consumer form of the fp16-split convolution (conv_pc.hip): eight consumer waves that only run the MFMA loop + four producer
 // waves that stage x.  launch_conv hands eligible launches (>= 5 row tiles, fp16-split precision, no masks / strides / phases) to it
 // unless DMEL_CONV_PC=0.  Bit-identical to conv_bf16_kernel<NP = 2>.
-bool conv_pc_eligible(const PackedConv& pc, const ConvRun& r);
+bool conv_pc_eligible(const PackedConv& pc, const ConvRun& r, bool any_size = false);      // any_size: also launches of < 128 workgroups (tests: DMEL_CONV_PC=2)
 int launch_conv_pc(const PackedConv& pc, const ConvRun& r, hipStream_t stream);
 
 // ---- training path (train_ops.hip, conv_bwd.hip) --------------------------------------------------------------
