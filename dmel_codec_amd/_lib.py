@@ -123,6 +123,7 @@ PROTOTYPES = {
     "dmel_bigvgan_finalize": (C.c_int, [vp]),
     "dmel_bigvgan_workspace_bytes": (C.c_size_t, [vp, C.c_int, C.c_int64]),
     "dmel_bigvgan_set_streams": (C.c_int, [vp, C.c_int]),
+    "dmel_stft_set_exclusive_cu": (C.c_int, [C.c_int]),
     "dmel_bigvgan_set_precision": (C.c_int, [vp, C.c_int]),
     "dmel_bigvgan_forward": (C.c_int, [vp, vp, vp, C.c_int, C.c_int64, vp, C.c_size_t, vp]),
     "dmel_conv_create": (C.c_int, [C.POINTER(vp), vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]),

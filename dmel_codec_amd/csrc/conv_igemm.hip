@@ -409,7 +409,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
   constexpr int NIT = RPW * NPASS;                       // items per thread per chunk
   constexpr int PSZ = KG * XS;                           // uint4 per piece
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  uint4* Xb = reinterpret_cast<uint4*>(smem);            // [2][NP][KG][XS] x 16 bytes
+#ifndef DMEL_CONV_LDS_PAD
+#define DMEL_CONV_LDS_PAD 0      // debug: bytes of unused LDS in front of and behind the kernel's own
+#endif
+  constexpr int kLdsPad = ((size_t)2 * NP * KG * XS * 16 + 2 * DMEL_CONV_LDS_PAD <= 65536) ? DMEL_CONV_LDS_PAD : 0;
+  uint4* Xb = reinterpret_cast<uint4*>(smem) + kLdsPad / 16;            // [2][NP][KG][XS] x 16 bytes
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wave_m = wave / WAVES_N, wave_n = wave % WAVES_N;
@@ -787,7 +791,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N, NP == 2 ? 2 : 1) void conv_
 template <int WM, int WN, int MT, int NT, int MODE, int HALO, int NP, int KG, int PS = 0>
 static int launch_b16k(const KArgs& ka, int B, int mblocks, hipStream_t st) {
   constexpr int BN = WN * NT * 32;
-  constexpr size_t lds = (size_t)2 * NP * KG * (BN + HALO) * 16;
+#ifndef DMEL_CONV_LDS_PAD
+#define DMEL_CONV_LDS_PAD 0
+#endif
+  constexpr size_t lds0 = (size_t)2 * NP * KG * (BN + HALO) * 16;
+  constexpr size_t lds = lds0 + (lds0 + 2 * DMEL_CONV_LDS_PAD <= 65536 ? 2 * DMEL_CONV_LDS_PAD : 0);
   static_assert(lds <= 64 * 1024, "bf16 conv tile exceeds the default dynamic LDS limit");
   KArgs k2 = ka;
   dim3 grid;
@@ -809,10 +817,13 @@ template <int WM, int WN, int MT, int NT, int MODE, int NP> static int launch_b1
   return launch_b16k<WM, WN, MT, NT, MODE, 64, NP, KGT>(ka, B, mblocks, st);
 }
 
+#ifndef DMEL_TILE5_NARROW
+#define DMEL_TILE5_NARROW 1      // tile 5 = 128 x 32 (four waves of 32 x 32): the few-column launches of pick_tile_bf16; 0: the old 64 x 128 (2,1,1,4), never chosen
+#endif
 template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int tile, int B, hipStream_t st) {
-  const int bm[8] = {128, 128, 64, 32, 128, 64, 128, 256};
+  const int bm[8] = {128, 128, 64, 32, 128, DMEL_TILE5_NARROW ? 128 : 64, 128, 256};
   // bf16 tiles: 0: 128x128 (2,2,2,2), 1: 128x96 (4,1,1,3), 2: 64x128 (2,2,1,2), 3: 32x256 (1,4,1,2), 4: 128x128 (4,1,1,4),
-  // 5: 64x128 (2,1,1,4), 6: 128x64 (4,1,1,2), 7: 256x96 (8,1,1,3: eight waves)
+  // 5: 128x32 (4,1,1,1) [64x128 (2,1,1,4) with DMEL_TILE5_NARROW=0], 6: 128x64 (4,1,1,2), 7: 256x96 (8,1,1,3: eight waves)
   const int mblocks = (ka.mtiles * 32 + bm[tile] - 1) / bm[tile];
   switch (tile) {
     case 0: return launch_b16<2, 2, 2, 2, MODE, NP>(ka, B, mblocks, st);
@@ -822,7 +833,11 @@ template <int MODE, int NP> static int launch_mode_bf16(const KArgs& ka, int til
     case 4: return launch_b16<4, 1, 1, 4, MODE, NP>(ka, B, mblocks, st);
     case 6: return launch_b16<4, 1, 1, 2, MODE, NP>(ka, B, mblocks, st);
     case 7: return launch_b16<8, 1, 1, 3, MODE, NP>(ka, B, mblocks, st);
+#if DMEL_TILE5_NARROW
+    default: return launch_b16<4, 1, 1, 1, MODE, NP>(ka, B, mblocks, st);      // 128 x 32 (four waves of 32 x 32)
+#else
     default: return launch_b16<2, 1, 1, 4, MODE, NP>(ka, B, mblocks, st);
+#endif
   }
 }
 
@@ -848,11 +863,17 @@ static int pick_tile_bf16(int mtiles, int64_t T, int np, int steps, int B) {
   // chip.  The 128 x 64 tile (four waves) makes 2-3x as many.  Every tile accumulates K in the same order: same bits, so a streamed chunk
   // still equals the whole-sequence decode (tests).  Measured (tools/bench_stream.py, batch 1, pipelined): 64-token chunks 480 -> 589
   // audio-s/s, 128-token 877 -> 1025 (profiles/r03_stream.txt).
-  if (np == 2 && mtiles >= 4 && t != 6) {
-    static const int bm[8] = {128, 128, 64, 32, 128, 64, 128, 256}, bn[8] = {128, 96, 128, 256, 128, 128, 64, 96};
-    const int64_t wgs = (int64_t)((mtiles * 32 + bm[t] - 1) / bm[t]) * ((T + bn[t] - 1) / bn[t]) * B;
+  if (np == 2 && mtiles >= 4) {
+    static const int bm[8] = {128, 128, 64, 32, 128, DMEL_TILE5_NARROW ? 128 : 64, 128, 256};
+    static const int bn[8] = {128, 96, 128, 256, 128, DMEL_TILE5_NARROW ? 32 : 128, 64, 96};
+    auto wgs = [&](int tt) { return (int64_t)((mtiles * 32 + bm[tt] - 1) / bm[tt]) * ((T + bn[tt] - 1) / bn[tt]) * B; };
     static const bool off = [] { const char* f = getenv("DMEL_CONV_SMALLN"); return f && f[0] == '0'; }();
-    if (wgs < 128 && !off) t = 6;
+    if (!off && wgs(t) < 128) {
+      t = 6;
+      // ... and the 128 x 32 tile where even that leaves most CUs idle (a 64-token chunk: 44 -> 88 workgroups; forced on every launch it
+      // measured 580 -> 634 audio-s/s at 64-token chunks, 299 -> 332 at 32)
+      if (DMEL_TILE5_NARROW && wgs(6) < 128) t = 5;
+    }
   }
   return t;
 }

@@ -14,6 +14,8 @@
 // Algorithmic HBM bytes per frame: hop*4 read + n_mels*4 written.
 #include "common.h"
 
+#include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <mutex>
 
@@ -25,6 +27,12 @@ namespace dmel {
 #endif
 #ifndef DMEL_STFT_REGTAB_MAXP
 #define DMEL_STFT_REGTAB_MAXP 8
+#endif
+#ifndef DMEL_STFT_LDS_PAD
+#define DMEL_STFT_LDS_PAD 0      // debug: bytes of unused LDS in front of and behind the kernel's own
+#endif
+#ifndef DMEL_STFT_FULL_TILE
+#define DMEL_STFT_FULL_TILE 0      // debug: 1 = LDS sized for 128 bands whatever the plan (the round-2 allocation)
 #endif
 #ifndef DMEL_STFT_WPE
 #define DMEL_STFT_WPE 0
@@ -125,10 +133,22 @@ __device__ __forceinline__ int64_t reflect_index(int64_t s, int64_t L) {
 // LDS operations of one wave execute in order, so the phases of a frame (which only exchange data between the lanes of
 // ONE wave) need a wave-local fence, not a workgroup barrier: the four waves of a workgroup run their frames
 // independently and meet once, before the coalesced tile store.
+#ifndef DMEL_STFT_SYNC
+#define DMEL_STFT_SYNC 0      // debug: 1 = explicit s_waitcnt lgkmcnt(0) in wave_sync, 2 = workgroup-scope fences
+#endif
 __device__ __forceinline__ void wave_sync() {
+#if DMEL_STFT_SYNC == 2
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#if DMEL_STFT_SYNC == 1
+  __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0), vmcnt / expcnt untouched
+#endif
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
 }
 
 constexpr int kMaxMelW = 2304;   // non-zero mel weights (each FFT bin feeds at most two bands: <= 2*1025)
@@ -147,8 +167,12 @@ __global__ __launch_bounds__(kThreads) void stft_logmel_kernel(StftTables tb, co
                                                           int hop, int pad, int n_mels, int mel_passes) {
   constexpr int H = 64 * P, N = 128 * P, U = (P + 7) / 8, EX = P * 72, NR = P / 2 + 1;
   extern __shared__ __attribute__((aligned(16))) float smem_stft[];
-  cf* buf_all = reinterpret_cast<cf*>(smem_stft);                 // [kWaves][EX]   exchange buffer, reused by every pass
-  float* mag_all = smem_stft + 2 * kWaves * EX;                   // [kWaves][H+8]
+#ifndef DMEL_STFT_LDS_PAD
+#define DMEL_STFT_LDS_PAD 0      // debug: bytes of unused LDS in front of and behind the kernel's own
+#endif
+  float* const smem_base = smem_stft + DMEL_STFT_LDS_PAD / 4;
+  cf* buf_all = reinterpret_cast<cf*>(smem_base);                 // [kWaves][EX]   exchange buffer, reused by every pass
+  float* mag_all = smem_base + 2 * kWaves * EX;                   // [kWaves][H+8]
   float* chw = mag_all + kWaves * (H + 8);                        // [mel_passes * 64][kMelChunk] chunk weights (LDS sized per plan)
   int* chk0 = reinterpret_cast<int*>(chw + mel_passes * 64 * kMelChunk);   // [mel_passes * 64] first bin of every chunk
   float (*tile)[kFramesPerWG + 1] = reinterpret_cast<float (*)[kFramesPerWG + 1]>(chk0 + mel_passes * 64);   // [n_mels][33]
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(kThreads) void stft_logmel_kernel(StftTables tb, co
 // the output tile is sized by the plan's band count (80 bands at n_fft = 1024: 48.6 KB, three workgroups per CU instead of two)
 template <int P> static size_t stft_lds_bytes(int mel_passes = kMaxMelPasses, int n_mels = kMaxMels) {
   return (size_t)(2 * kWaves * P * 72 + kWaves * (64 * P + 8) + mel_passes * 64 * (kMelChunk + 1) + n_mels * (kFramesPerWG + 1)) *
-         sizeof(float);
+             sizeof(float) + 2 * DMEL_STFT_LDS_PAD;
 }
 
 }  // namespace dmel
@@ -509,6 +533,32 @@ extern "C" int64_t dmel_stft_num_frames(const dmel_stft_plan* p, int64_t L) {
   return 1 + (padded - p->n_fft) / p->hop;
 }
 
+// ---- one workgroup per CU, and no other LDS user beside it (round 3) -------------------------------------------------------------
+// Measured (tools/dbg_lanes5.py / dbg_lanes7.py, profiles/r03_stft_concurrency.txt): when workgroups of this kernel share a CU with
+// workgroups of the convolution kernels -- which only happens when the two are launched from different streams -- 3-11 % of the launches
+// come back with ONE frame wrong (a subset of its bands, or all of them; values near the right ones).  What was ruled out: LDS overflow on
+// either side (8 KB guard regions; the hardware isolates LDS between workgroups: tools/probe/ldsoob.hip), residue in registers or LDS
+// (tools/probe/poison.hip), LDS ordering inside the wave (explicit lgkmcnt(0), workgroup-scope fences), stale cache lines (the wrong
+// values are not what the address held before), the LDS size of this round.  rocBLAS GEMMs, the activation kernel, torch element-wise
+// kernels and this kernel itself as the neighbour do not trigger it.  The mechanism is not understood; the cure is to keep the two apart:
+// with dmel_stft_set_exclusive_cu(1) a launch asks for kExclusiveLds bytes of LDS, so that a CU holding one of its workgroups has no room
+// for a workgroup of any kernel that uses more than 8 KB of LDS (every convolution kernel does), and the other way round.  One workgroup
+// per CU instead of three: nothing for the 96-workgroup launch of the codec, 2.5x slower at 256 x 60 s -- hence a switch, set by
+// dmel_codec_amd.pipeline.CodecLanes (several batches in flight on their own streams) and off otherwise.
+static std::atomic<int> g_exclusive_cu{0};
+constexpr size_t kExclusiveLds = 152 * 1024;
+extern "C" int dmel_stft_set_exclusive_cu(int on) {
+  g_exclusive_cu.store(on ? 1 : 0);
+  return DMEL_OK;
+}
+template <int P> static size_t stft_launch_lds(const dmel_stft_plan* p) {
+  const size_t need = stft_lds_bytes<P>(p->mel_passes, DMEL_STFT_FULL_TILE ? kMaxMels : p->n_mels);
+  if (!g_exclusive_cu.load()) return need;
+  static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&stft_logmel_kernel<P>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)kExclusiveLds) == hipSuccess;
+  return ok ? std::max(need, kExclusiveLds) : need;
+}
+
 extern "C" int dmel_stft_logmel_f32(const dmel_stft_plan* p, const float* audio, int64_t row_stride, const int64_t* lengths,
                                     float* out, int B, int64_t L, void* stream) {
   DMEL_CHECK_ARG(out, "NULL argument");
@@ -533,15 +583,15 @@ extern "C" int dmel_stft_f32(const dmel_stft_plan* p, const float* audio, int64_
     ProfScope ps("stft_logmel", s, 0.0, (double)B * (4.0 * (double)L + 4.0 * p->n_mels * (double)T));
     switch (p->n_fft) {
       case 512:
-        hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(kThreads), stft_lds_bytes<4>(p->mel_passes, p->n_mels), s, tb, audio, row_stride, lengths, out,
+        hipLaunchKernelGGL(stft_logmel_kernel<4>, grid, dim3(kThreads), stft_launch_lds<4>(p), s, tb, audio, row_stride, lengths, out,
                            linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
         break;
       case 1024:
-        hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(kThreads), stft_lds_bytes<8>(p->mel_passes, p->n_mels), s, tb, audio, row_stride, lengths, out,
+        hipLaunchKernelGGL(stft_logmel_kernel<8>, grid, dim3(kThreads), stft_launch_lds<8>(p), s, tb, audio, row_stride, lengths, out,
                            linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
         break;
       default:
-        hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(kThreads), stft_lds_bytes<16>(p->mel_passes, p->n_mels), s, tb, audio, row_stride, lengths,
+        hipLaunchKernelGGL(stft_logmel_kernel<16>, grid, dim3(kThreads), stft_launch_lds<16>(p), s, tb, audio, row_stride, lengths,
                            out, linear, L, T, p->hop, p->pad, p->n_mels, p->mel_passes);
     }
   }

@@ -61,6 +61,11 @@ class CodecLanes:
         if dev.type != "cuda":
             raise RuntimeError("CodecLanes needs the codec on a CUDA device (there is no CPU path)")
         self.device = dev
+        if n_lanes > 1:
+            # kernels of different lanes share CUs; the STFT kernel must not share one with the convolution kernels (include/dmel_hip.h,
+            # dmel_stft_set_exclusive_cu: a measured corruption of single frames, cured by giving its workgroups a CU's whole LDS)
+            from . import _lib
+            _lib.check(_lib.lib().dmel_stft_set_exclusive_cu(1), "stft_set_exclusive_cu")
         self.codecs = [codec] + [copy.deepcopy(codec).eval() for _ in range(n_lanes - 1)]
         with torch.cuda.device(dev):
             self.streams: List[torch.cuda.Stream] = [torch.cuda.Stream(device=dev) for _ in range(n_lanes)]

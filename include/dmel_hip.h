@@ -96,6 +96,13 @@ int64_t dmel_stft_num_frames(const dmel_stft_plan* plan, int64_t L);
  * of codec_lit_modules.py:492-506 fused in). */
 int dmel_stft_logmel_f32(const dmel_stft_plan* plan, const float* audio, int64_t audio_row_stride,
                          const int64_t* lengths, float* out, int B, int64_t L, void* stream);
+
+/* Several streams on one GPU (round 3; dmel_codec_amd.pipeline.CodecLanes sets it): on != 0 makes every later STFT launch of the process ask for
+ * 152 KB of LDS, i.e. one workgroup per CU and no room beside it for a workgroup of the convolution kernels.  Launched from different
+ * streams, the two kinds of workgroup otherwise end up on one CU, and 3-11 % of the STFT launches then return one wrong frame (measured,
+ * mechanism not understood: csrc/stft_logmel.hip, profiles/r03_stft_concurrency.txt).  No reference counterpart (utils/spectrogram.py:58-79 is
+ * one torch.stft call on the current stream).  Costs nothing at the codec's sizes (<= 256 workgroups), 2.5x at 256 x 60 s. */
+int dmel_stft_set_exclusive_cu(int on);
 /* The same launch with the linear magnitudes sqrt(re^2 + im^2 + 1e-9) (utils/spectrogram.py:76) as a second, optional output:
  * linear (B, T, n_fft/2 + 1), frame-major so that every frame is one coalesced row; logmel_out may be NULL (then the mel stage is
  * skipped).  Consumer: the multi-resolution STFT loss BASELINE.json's north_star names (absent from the reference). */
