@@ -348,9 +348,16 @@ def main() -> None:
     elapsed = timed(lane_step if len(lanes) > 1 else one_step)
     rank_elapsed = per_rank_times(dist, elapsed, dev)
     elapsed = max_over_ranks(dist, elapsed, dev)
+    lanes_ids_ok = None
     if elapsed_one_lane is not None:
         elapsed_one_lane = max_over_ranks(dist, elapsed_one_lane, dev)
         ids, _, wav = last["r"].wait()
+        # the token ids do not depend on the decoder's noise: the batch that went through a lane with others in flight must give exactly the
+        # ids of the same batch on its own (a kernel-level interference between lanes would show here: profiles/r03_stft_concurrency.txt)
+        torch.cuda.synchronize()
+        lanes_ids_ok = bool(torch.equal(ids, last["ids"]))
+        if not lanes_ids_ok:
+            raise SystemExit("bench.py: token ids of a batch processed with other batches in flight differ from the same batch alone")
     else:
         ids, wav = last["ids"], last["wav"]
 
@@ -430,7 +437,7 @@ def main() -> None:
                                    f"WaveNet 20+20 layers, BigVGAN-base, batch {args.batch} x {args.seconds:g} s per GPU",
                        "parallelism": f"{world} x independent utterance shards, no collective; {len(lanes)} independent batch(es) in flight "
                                       "per GPU (dmel_codec_amd.pipeline.CodecLanes)",
-                       "lanes": len(lanes), "vocoder_streams": args.streams},
+                       "lanes": len(lanes), "vocoder_streams": args.streams, "lane_ids_equal_single_batch_ids": lanes_ids_ok},
             "one_batch_at_a_time": ({"value": round(job_rate(world, args.batch, args.seconds, args.steps, elapsed_one_lane), 2),
                                      "ms_per_step": round(1e3 * elapsed_one_lane / args.steps, 3)} if elapsed_one_lane is not None else None),
             "roofline": {"bound": "mfma", "kernel": kernel,
